@@ -1,0 +1,11 @@
+"""Import alias: `import mdm_amd` == the package in ./motiondiffusion-moe_amd/ (whose directory name,
+fixed by the project layout, is not a valid Python identifier)."""
+import importlib
+import os
+import sys
+
+_root = os.path.dirname(os.path.abspath(__file__))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+_pkg = importlib.import_module("motiondiffusion-moe_amd")
+sys.modules[__name__] = _pkg

@@ -1,0 +1,64 @@
+"""Build libmdm_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build(); also runnable:
+    python motiondiffusion-moe_amd/build.py [--force]
+hipcc cross-compiles without a GPU.  Objects go to csrc/build/, the library next to this file so it
+travels to the GPU box with the source snapshot."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libmdm_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+         "-Wno-unused-result"]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        if force or _newer([s] + hdrs, o):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = ["hipcc"] + FLAGS + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[mdm build] compiled {os.path.basename(s)}", flush=True)
+        return o
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(cc, jobs))
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if force or jobs or _newer(objs, LIB):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[mdm build] linked {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

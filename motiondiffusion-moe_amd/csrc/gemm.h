@@ -1,0 +1,52 @@
+// Fused MFMA GEMM family:  C = epilogue( A[M,K] * W[N,K]^T )  on gfx950.
+// One kernel template covers dense Linear layers, the Performer/cross-attention contractions
+// (batched, operands read straight out of activation tensors) and the grouped expert GEMMs.
+// The descriptor is the public C struct (include/mdm_hip.h).
+#pragma once
+#include "mdm_common.h"
+#include "mdm_hip.h"
+
+namespace mdm {
+
+typedef MdmOperand Operand;
+typedef MdmGemmDesc GemmArgs;
+
+enum OperandKind { OP_F32_ROW = MDM_OP_F32_ROW, OP_F32_KSTRIDE = MDM_OP_F32_KSTRIDE, OP_BF16_ROW = MDM_OP_BF16_ROW };
+enum Act { ACT_NONE = MDM_ACT_NONE, ACT_GELU = MDM_ACT_GELU, ACT_SILU = MDM_ACT_SILU, ACT_FEAT = MDM_ACT_FEAT };
+
+inline GemmArgs gemm_defaults(int precision) {
+  GemmArgs g = {};
+  g.batch = 1;
+  g.nb2 = 1;
+  g.alpha = 1.f;
+  g.out_scale = 1.f;
+  g.r1_scale = 1.f;
+  g.precision = precision;
+  return g;
+}
+inline Operand op_f32(const float* p, int64_t ld) {
+  Operand o = {};
+  o.p = p;
+  o.ld = ld;
+  o.kind = OP_F32_ROW;
+  return o;
+}
+inline Operand op_f32_kstride(const float* p, int64_t ld) {
+  Operand o = {};
+  o.p = p;
+  o.ld = ld;
+  o.kind = OP_F32_KSTRIDE;
+  return o;
+}
+inline Operand op_bf16(const uint16_t* hi, const uint16_t* lo, int64_t ld) {
+  Operand o = {};
+  o.p = hi;
+  o.p_lo = lo;
+  o.ld = ld;
+  o.kind = OP_BF16_ROW;
+  return o;
+}
+
+int gemm(const GemmArgs& a, hipStream_t stream);
+
+}  // namespace mdm

@@ -1,0 +1,72 @@
+// Common device helpers for the gfx950 (MI355X) denoiser kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mdm_hip.h"
+
+namespace mdm {
+
+// status codes: include/mdm_hip.h (MDM_OK, MDM_ERR_*)
+
+#define MDM_RETURN_IF_LAUNCH_FAILED()                 \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) return (int)MDM_ERR_LAUNCH; \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));  // MFMA A/B fragment: 8 bf16 in 4 VGPRs
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// round-to-nearest-even f32 -> bf16 pair (lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float bf16_lo_f32(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi_f32(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// split (a,b) into bf16 "hi" and bf16 "lo" = rn(x - hi): hi+lo carries ~16 mantissa bits
+__device__ __forceinline__ void split_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16(a, b);
+  lo = pack_bf16(a - bf16_lo_f32(hi), b - bf16_hi_f32(hi));
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reductions over aligned sub-groups of W lanes (W power of two <= 64)
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (8 XCDs, round-robin dispatch).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+}  // namespace mdm

@@ -1,0 +1,88 @@
+"""Thin host wrappers over the C ABI: one Python function per kernel family.
+Only plumbing lives here (pointer/stride marshalling); all arithmetic is in csrc/."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+class PackedWeight:
+    """bf16 planes of an fp32 [N, K] weight, K zero-padded to a multiple of 32.
+    `lo` carries rn(w - hi) for the bf16x3 (fp32-grade) mode."""
+
+    def __init__(self, w: torch.Tensor, with_lo: bool = True):
+        L.require_cuda(w)
+        w = w.detach().to(torch.float32)
+        lead = w.shape[:-2]
+        n, k = w.shape[-2], w.shape[-1]
+        w2 = w.reshape(-1, k).contiguous()
+        kp = (k + 31) // 32 * 32
+        self.N, self.K, self.Kp = n, k, kp
+        self.hi = torch.empty((w2.shape[0], kp), dtype=torch.bfloat16, device=w.device)
+        self.lo = torch.empty_like(self.hi) if with_lo else None
+        L.check(L.lib().mdm_pack_bf16(C.c_void_p(w2.data_ptr()), C.c_int64(k), C.c_int64(w2.shape[0]), C.c_int64(k),
+                                      C.c_void_p(self.hi.data_ptr()), C.c_void_p(L.ptr(self.lo)), C.c_int64(kp),
+                                      C.c_void_p(L.stream_ptr())), "mdm_pack_bf16")
+        self.lead = tuple(lead)
+
+    def operand(self, row_offset: int = 0) -> L.Operand:
+        o = L.Operand()
+        o.p = self.hi.data_ptr() + row_offset * self.Kp * 2
+        o.p_lo = (self.lo.data_ptr() + row_offset * self.Kp * 2) if self.lo is not None else 0
+        o.ld = self.Kp
+        o.kind = L.OP_BF16_ROW
+        return o
+
+
+def f32_operand(t: torch.Tensor, ld: int, kind: int = L.OP_F32_ROW, offset: int = 0) -> L.Operand:
+    o = L.Operand()
+    o.p = t.data_ptr() + 4 * offset
+    o.ld = ld
+    o.kind = kind
+    return o
+
+
+def gemm_desc(precision: int) -> L.GemmDesc:
+    d = L.GemmDesc()
+    d.batch, d.nb2 = 1, 1
+    d.alpha, d.out_scale, d.r1_scale = 1.0, 1.0, 1.0
+    d.precision = precision
+    return d
+
+
+def run_gemm(d: L.GemmDesc):
+    L.check(L.lib().mdm_gemm(C.byref(d), C.c_void_p(L.stream_ptr())), "mdm_gemm")
+
+
+def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
+           alpha: float = 1.0, out_scale: float = 1.0, colscale=None, rowscale=None, r1=None, r1_scale: float = 1.0,
+           r1_mod: int = 0, r2=None, precision: int = 3, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epilogue(x @ w^T): the fused Linear used throughout the denoiser."""
+    L.require_cuda(x)
+    K = x.shape[-1]
+    assert K == w.K, (K, w.K)
+    x2 = x.reshape(-1, K)
+    assert x2.stride(-1) == 1
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, w.N), dtype=torch.float32, device=x.device)
+    d = gemm_desc(precision)
+    d.A = f32_operand(x2, x2.stride(0))
+    d.W = w.operand()
+    d.M, d.N, d.K = M, w.N, K
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    d.bias = L.ptr(bias)
+    d.act, d.alpha, d.out_scale = act, alpha, out_scale
+    d.colscale, d.rowscale = L.ptr(colscale), L.ptr(rowscale)
+    if r1 is not None:
+        r1 = r1.reshape(-1, w.N)
+        d.R1, d.ldr1, d.r1_scale, d.r1_mod = r1.data_ptr(), r1.stride(0), r1_scale, r1_mod
+    if r2 is not None:
+        r2 = r2.reshape(-1, w.N)
+        d.R2, d.ldr2 = r2.data_ptr(), r2.stride(0)
+    run_gemm(d)
+    return out.reshape(*x.shape[:-1], w.N)

@@ -1,0 +1,171 @@
+"""GPU: the fused MFMA GEMM (csrc/gemm.hip) through the C ABI against a torch fp64 reference."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from conftest import pkg, rel_inf
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    return pkg("_lib"), pkg("ops")
+
+
+def _rand(*shape, seed=0, dev="cuda"):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1).to(dev)
+
+
+TOL = {1: 2e-2, 3: 2e-5}
+
+
+@pytest.mark.parametrize("precision", [1, 3])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 512), (200, 263, 512), (70, 512, 263), (1, 96, 40),
+                                   (392, 1536, 512)])
+def test_linear_plain(M, N, K, precision):
+    L, ops = _mods()
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
+    pw = ops.PackedWeight(w)
+    y = ops.linear(x, pw, b, precision=precision)
+    ref = (x.double() @ w.double().T + b.double()).float()
+    assert rel_inf(y.cpu(), ref.cpu()) < TOL[precision]
+
+
+def test_asymmetric_identity_layout():
+    """A = I with asymmetric W catches row/col swaps in the MFMA C/D map."""
+    L, ops = _mods()
+    n = 128
+    x = torch.eye(n, device="cuda")
+    w = (torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n) % 251) - 125.0  # exact in bf16
+    y = ops.linear(x, ops.PackedWeight(w), None, precision=1)
+    assert torch.equal(y, w.T.contiguous())
+
+
+@pytest.mark.parametrize("precision", [1, 3])
+def test_epilogue_options(precision):
+    L, ops = _mods()
+    M, N, K, T = 150, 200, 96, 50
+    x, w, b = _rand(M, K, seed=4), _rand(N, K, seed=5), _rand(N, seed=6)
+    cs, rs = _rand(N, seed=7), _rand(M, seed=8)
+    r1, r2 = _rand(T, N, seed=9), _rand(M, N, seed=10)
+    pw = ops.PackedWeight(w)
+    lin = x.double() @ w.double().T + b.double()
+    for act, fn in [(L.ACT_NONE, lambda v: v), (L.ACT_GELU, lambda v: torch.nn.functional.gelu(v)),
+                    (L.ACT_SILU, lambda v: torch.nn.functional.silu(v)),
+                    (L.ACT_FEAT, lambda v: 0.1 * torch.exp(v.clamp(-15, 15)))]:
+        y = ops.linear(x, pw, b, act=act, alpha=0.7, out_scale=0.3, colscale=cs, rowscale=rs, r1=r1, r1_scale=0.25,
+                       r1_mod=T, r2=r2, precision=precision)
+        ref = fn(0.7 * lin) * 0.3 * cs.double()[None] * rs.double()[:, None]
+        ref = ref + 0.25 * r1.double()[torch.arange(M, device="cuda") % T] + r2.double()
+        assert rel_inf(y.cpu(), ref.float().cpu()) < TOL[precision], act
+
+
+@pytest.mark.parametrize("precision", [1, 3])
+def test_batched_kstride_and_rowmajor_operands(precision):
+    """The Performer contractions: KV^T[b,h] = 0.1 * V^T Kf (both operands K-strided) and num = 0.1 * Qf KV."""
+    L, ops = _mods()
+    B, H, S, dh, m = 3, 4, 52, 128, 128
+    D = H * dh
+    qkv = _rand(B * S, 3 * D, seed=11)
+    phi = _rand(B * S, 2 * H * m, seed=12).abs()
+    kvt = torch.empty(B, H, dh, m, device="cuda")
+    d = ops.gemm_desc(precision)
+    d.A = ops.f32_operand(qkv, 3 * D, L.OP_F32_KSTRIDE, offset=2 * D)
+    d.A.bs1, d.A.bs2 = S * 3 * D, dh
+    d.W = ops.f32_operand(phi, 2 * H * m, L.OP_F32_KSTRIDE, offset=H * m)
+    d.W.bs1, d.W.bs2 = S * 2 * H * m, m
+    d.M, d.N, d.K = dh, m, S
+    d.batch, d.nb2 = B * H, H
+    d.C, d.ldc, d.c_bs1, d.c_bs2 = kvt.data_ptr(), m, H * dh * m, dh * m
+    d.out_scale = 0.1
+    ops.run_gemm(d)
+    v = qkv.view(B, S, 3, H, dh)[:, :, 2].double()  # (B,S,H,dh)
+    kf = phi.view(B, S, 2, H, m)[:, :, 1].double()
+    ref = 0.1 * torch.einsum("bshd,bshm->bhdm", v, kf)
+    assert rel_inf(kvt.cpu(), ref.float().cpu()) < TOL[precision]
+    # num[b,s,h,:] = 0.1 * qf[b,s,h,:] @ KV[b,h]  with W = KV^T rows (dh x m), row-major fp32
+    num = torch.empty(B * S, D, device="cuda")
+    d = ops.gemm_desc(precision)
+    d.A = ops.f32_operand(phi, 2 * H * m)
+    d.A.bs1, d.A.bs2 = S * 2 * H * m, m
+    d.W = ops.f32_operand(kvt, m)
+    d.W.bs1, d.W.bs2 = H * dh * m, dh * m
+    d.M, d.N, d.K = S, dh, m
+    d.batch, d.nb2 = B * H, H
+    d.C, d.ldc, d.c_bs1, d.c_bs2 = num.data_ptr(), D, S * D, dh
+    d.out_scale = 0.1
+    ops.run_gemm(d)
+    qf = phi.view(B, S, 2, H, m)[:, :, 0].double()
+    ref2 = 0.1 * torch.einsum("bshm,bhdm->bshd", qf, kvt.double()).reshape(B * S, D)
+    assert rel_inf(num.cpu(), ref2.float().cpu()) < TOL[precision]
+
+
+@pytest.mark.parametrize("precision", [1, 3])
+def test_grouped_gather_feature_rows(precision):
+    """Expert-style grouped GEMM with gathered rows + grouped rows-per-token addressing with key masking."""
+    L, ops = _mods()
+    E, D, F_, Mtok = 5, 96, 160, 333
+    x = _rand(Mtok, D, seed=13)
+    w = _rand(E, F_, D, seed=14)
+    b = _rand(E, F_, seed=15)
+    g = torch.Generator().manual_seed(3)
+    counts = torch.tensor([0, 130, 1, 257, 61])
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = counts.cumsum(0)
+    tot = int(off[-1])
+    gather = torch.randint(0, Mtok, (tot,), generator=g, dtype=torch.int32)
+    pw = ops.PackedWeight(w)
+    out = torch.zeros(tot, F_, device="cuda")
+    d = ops.gemm_desc(precision)
+    d.A = ops.f32_operand(x, D)
+    gd = gather.cuda()
+    d.A.gather = gd.data_ptr()
+    d.W = pw.operand()
+    d.W.bs1 = F_ * pw.Kp
+    od = off.cuda()
+    d.goff, d.ngroups = od.data_ptr(), E
+    d.M, d.N, d.K = tot, F_, D
+    bd = b.contiguous()
+    d.bias, d.bias_bs = bd.data_ptr(), F_
+    d.C, d.ldc = out.data_ptr(), F_
+    d.act = L.ACT_GELU
+    ops.run_gemm(d)
+    ref = torch.empty(tot, F_, dtype=torch.float64)
+    for e in range(E):
+        r = slice(int(off[e]), int(off[e + 1]))
+        xe = x.cpu().double()[gather[r].long()]
+        ref[r] = torch.nn.functional.gelu(xe @ w[e].cpu().double().T + b[e].cpu().double())
+    assert rel_inf(out.cpu(), ref.float()) < TOL[precision]
+
+    # feature map over (token, slot) rows: slots [0,H) are queries, [H,2H) keys, masked past length
+    B, S, H, dh, m = 2, 10, 2, 32, 32
+    qkv = _rand(B * S, 3 * H * dh, seed=16)
+    P = _rand(dh, m, seed=17) * 0.3
+    pw = ops.PackedWeight(P.T.contiguous())
+    lens = torch.tensor([10, 6], dtype=torch.int32, device="cuda")
+    phi = torch.empty(B * S, 2 * H, m, device="cuda")
+    d = ops.gemm_desc(precision)
+    d.A = ops.f32_operand(qkv, dh)
+    d.A.rpg, d.A.gstride = 2 * H, 3 * H * dh
+    d.W = pw.operand()
+    d.M, d.N, d.K = B * S * 2 * H, m, dh
+    d.C, d.ldc = phi.data_ptr(), m
+    d.act = L.ACT_FEAT
+    d.feat_len, d.feat_S, d.feat_rpt, d.feat_kslot = lens.data_ptr(), S, 2 * H, H
+    ops.run_gemm(d)
+    z = qkv.view(B, S, 3, H, dh)[:, :, :2].double() @ P.double()
+    ref = 0.1 * torch.exp(z.clamp(-15, 15))
+    mask = (torch.arange(S, device="cuda")[None] < lens[:, None]).double()
+    ref[:, :, 1] *= mask[:, :, None, None]
+    assert rel_inf(phi.cpu(), ref.reshape(B * S, 2 * H, m).float().cpu()) < TOL[precision]
+
+
+def test_gemm_rejects_bad_args():
+    L, ops = _mods()
+    d = ops.gemm_desc(1)
+    assert L.lib().mdm_gemm(C.byref(d), C.c_void_p(0)) == 0  # empty problem is a no-op
+    d.M = d.N = d.K = 32
+    assert L.lib().mdm_gemm(C.byref(d), C.c_void_p(0)) == 1  # null operands
