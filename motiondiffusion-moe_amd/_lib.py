@@ -36,6 +36,62 @@ class GemmDesc(C.Structure):
                 ("feat_rpt", C.c_int32), ("feat_kslot", C.c_int32), ("precision", C.c_int32)]
 
 
+class Packed(C.Structure):
+    _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("ld", C.c_int64)]
+
+
+class Style(C.Structure):
+    _fields_ = [("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("out", Packed), ("out_b", C.c_void_p)]
+
+
+class Performer(C.Structure):
+    _fields_ = [("pre_w", C.c_void_p), ("pre_b", C.c_void_p), ("post_w", C.c_void_p), ("post_b", C.c_void_p),
+                ("qkv", Packed), ("qkv_b", C.c_void_p), ("hn_w", C.c_void_p), ("hn_b", C.c_void_p),
+                ("feat", Packed), ("proj0", Packed), ("proj3", Packed), ("proj0_b", C.c_void_p),
+                ("proj3_b", C.c_void_p), ("style", Style)]
+
+
+_P2 = C.c_void_p * 2
+
+
+class Layer(C.Structure):
+    _fields_ = [("dual_pre_w", C.c_void_p), ("dual_pre_b", C.c_void_p), ("dual_post_w", C.c_void_p),
+                ("dual_post_b", C.c_void_p), ("local", Performer), ("global_", Performer), ("skip", Packed),
+                ("skip_b", C.c_void_p),
+                ("ca_norm_w", C.c_void_p), ("ca_norm_b", C.c_void_p), ("ca_tnorm_w", C.c_void_p),
+                ("ca_tnorm_b", C.c_void_p), ("ca_q", Packed), ("ca_k", Packed), ("ca_v", Packed),
+                ("ca_q_b", C.c_void_p), ("ca_k_b", C.c_void_p), ("ca_v_b", C.c_void_p), ("ca_gvec", C.c_void_p),
+                ("ca_style", Style),
+                ("moe_ln_w", _P2), ("moe_ln_b", _P2), ("gate_w", _P2), ("gate_b", _P2), ("w1", Packed), ("w2", Packed),
+                ("b1", C.c_void_p), ("b2", C.c_void_p), ("usage", _P2), ("importance", _P2), ("ffn_style", Style),
+                ("sd_q", Packed), ("sd_k", Packed), ("sd_v", Packed), ("sd_out", Packed), ("sd_f1", Packed),
+                ("sd_f2", Packed), ("sd_q_b", C.c_void_p), ("sd_k_b", C.c_void_p), ("sd_v_b", C.c_void_p),
+                ("sd_out_b", C.c_void_p), ("sd_ln_w", C.c_void_p), ("sd_ln_b", C.c_void_p), ("sd_f1_b", C.c_void_p),
+                ("sd_f2_b", C.c_void_p)]
+
+
+_MODEL_PACKED = ["tmlp0", "tmlp2", "te0", "te2", "tproj", "gf_time", "gf_text", "gf_post0", "gf_post2", "text_proj",
+                 "joint", "down", "up", "out"]
+_MODEL_BIAS = ["tmlp0_b", "tmlp2_b", "te0_b", "te2_b", "tproj_b", "gf_time_b", "gf_text_b", "gf_post0_b", "gf_post2_b",
+               "text_proj_b", "joint_b", "down_b", "up_b2", "out_b"]
+
+
+class Model(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("D", "F", "Dt", "H", "E", "L", "feats", "num_frames")]
+                + [(n, Packed) for n in _MODEL_PACKED] + [(n, C.c_void_p) for n in _MODEL_BIAS]
+                + [("seq_emb", C.c_void_p), ("style_eph", Packed), ("style_eph_b", C.c_void_p),
+                   ("style_emb", Packed), ("style_emb_b", C.c_void_p), ("layers", C.POINTER(Layer))])
+
+
+class TextCache(C.Structure):
+    _fields_ = [("lin_at", C.c_void_p), ("sd_k", C.c_void_p), ("sd_v", C.c_void_p), ("B", C.c_int32),
+                ("N", C.c_int32)]
+
+
+BLOCK_DUAL, BLOCK_CROSS, BLOCK_MOE, BLOCK_SDCROSS, BLOCK_LAYER = 0, 1, 2, 3, 4
+TAB_ROWS = 7  # sqrt_recip_acp, sqrt_recipm1_acp, coef1, coef2, post_logvar_clipped, acp, acp_prev
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -45,14 +101,18 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mdm_version.restype = C.c_char_p
         for name in EXPORTS:
-            if name != "mdm_version":
+            if name == "mdm_workspace_bytes":
+                getattr(L, name).restype = C.c_int64
+            elif name != "mdm_version":
                 getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
 
 
 # every symbol include/mdm_hip.h declares (checked by tests/test_abi.py)
-EXPORTS = ["mdm_version", "mdm_gemm", "mdm_pack_bf16"]
+EXPORTS = ["mdm_version", "mdm_gemm", "mdm_pack_bf16", "mdm_workspace_bytes", "mdm_text_cache_build",
+           "mdm_denoiser_forward", "mdm_block_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
+           "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32"]
 
 
 def check(status: int, what: str = "mdm call"):

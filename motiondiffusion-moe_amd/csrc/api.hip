@@ -1,5 +1,6 @@
 // extern "C" surface of libmdm_hip.so (declared in include/mdm_hip.h).
 #include "gemm.h"
+#include "kernels.h"
 
 namespace mdm {
 namespace {
@@ -42,6 +43,16 @@ int mdm_pack_bf16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uin
                      lo, ld_dst);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
+}
+
+int mdm_fill_i64(int64_t* dst, int64_t n, const int32_t* src_dev, void* stream) {
+  if (!dst || !src_dev) return MDM_ERR_ARG;
+  return mdm::fill_i64(dst, n, src_dev, (hipStream_t)stream);
+}
+
+int mdm_add_i32(int32_t* dst, int32_t delta, void* stream) {
+  if (!dst) return MDM_ERR_ARG;
+  return mdm::add_i32(dst, delta, (hipStream_t)stream);
 }
 
 }  // extern "C"

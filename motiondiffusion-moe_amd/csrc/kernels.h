@@ -1,0 +1,48 @@
+// Internal launchers of the non-GEMM kernels (rowwise.hip).  All are stream-ordered, allocation free.
+#pragma once
+#include "mdm_common.h"
+
+namespace mdm {
+
+// rows of the fp32 schedule table handed to the sampler kernels: tab[row * steps + t]
+enum { TAB_SQRT_RECIP = 0, TAB_SQRT_RECIPM1 = 1, TAB_COEF1 = 2, TAB_COEF2 = 3, TAB_LOGVAR = 4, TAB_ACP = 5,
+       TAB_ACP_PREV = 6, TAB_ROWS = 7 };
+
+struct MoeGateParams {
+  const float* ln_w[2];
+  const float* ln_b[2];
+  const float* gate_w[2];  // (E, D) fp32
+  const float* gate_b[2];  // (E)
+  float* hn;               // (2, M, D) out: LN_b(x)
+  int* top_idx;            // (2, M, 2)
+  float* top_val;          // (2, M, 2)
+  int* hist;               // (2E) zeroed by moe_route
+  float* usage[2];         // optional persistent counters (E) each (switch_moe.py:71-92)
+  float* importance[2];
+  const int* forced_idx;   // optional (2, M, 2) injected routing (tests)
+};
+
+int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, float* y1, const float* w2,
+             const float* b2, float* y2, hipStream_t s);
+int style_in(const float* x, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw,
+             const float* sb, const float* sc, const int* pos4, float* out, hipStream_t s);
+int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, int* goff, int* cursor, int* perm,
+              float* rowscale, int* pos4, hipStream_t s);
+int head_norm(float* qkv, int64_t M, int H, int dh, const float* w, const float* b, hipStream_t s);
+int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const float* w, const float* b, float* out,
+           hipStream_t s);
+int head_softmax(float* q, int64_t units, int dh, hipStream_t s);
+int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
+int col_softmax(float* k, int B, int N, int D, hipStream_t s);
+int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s);
+int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s);
+int xattn_gate(const float* gate, const float* ag, int D, float* out, hipStream_t s);
+int halve_lengths(const int* len, int B, int* out, hipStream_t s);
+int fill_i64(int64_t* dst, int64_t n, const int* src, hipStream_t s);
+int add_i32(int* dst, int delta, hipStream_t s);
+int cfg_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n, const float* tab,
+             int ts, const int* t_ptr, int t_imm, float cfg_scale, float* x_out, float* x0_out, hipStream_t s);
+int ddim_step(const float* x, const float* eps, const float* noise, int64_t n, const float* tab, int ts,
+              const int* t_ptr, int t_imm, float eta, int clip, float* x_out, float* x0_out, hipStream_t s);
+
+}  // namespace mdm

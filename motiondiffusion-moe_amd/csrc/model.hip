@@ -1,0 +1,512 @@
+// Host-side orchestration of one denoiser forward: a straight-line sequence of stream-ordered kernel
+// launches (no allocation, no host sync) so that a whole sampling step can be captured into a hipGraph.
+// Reference arithmetic: text2motion/models/transformer.py:291-361 and the blocks it calls (cited inline).
+#include "gemm.h"
+#include "kernels.h"
+
+namespace mdm {
+namespace {
+
+#define MDM_TRY(expr)            \
+  do {                           \
+    int st__ = (expr);           \
+    if (st__ != MDM_OK) return st__; \
+  } while (0)
+
+struct Bump {  // carve the caller's workspace; with base == nullptr it only measures
+  uint8_t* base;
+  int64_t off = 0;
+  explicit Bump(void* b) : base((uint8_t*)b) {}
+  template <typename T>
+  T* take(int64_t n) {
+    off = (off + 255) & ~(int64_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * (int64_t)sizeof(T);
+    return p;
+  }
+};
+
+struct Work {
+  // token-major activations (M = B*T rows)
+  float *xa, *xb, *h0, *t1, *t2, *t3, *t4, *t5, *qkv, *phi, *kvt, *scr, *f1, *hn, *hid, *y2;
+  int *top_idx, *perm, *pos4, *hist, *goff, *cursor, *len_low;
+  float *top_val, *rowscale;
+  // stem (B rows)
+  float *s_a, *s_b, *s_c, *emb, *e1, *sc, *gvtmp;
+  // text cache scratch
+  float *tn, *kb, *vb;
+  int64_t bytes;
+};
+
+Work carve(const MdmModel& m, int B, int T, int N, void* ws) {
+  Work w;
+  Bump b(ws);
+  const int64_t M = (int64_t)B * T, D = m.D, F = m.F, Te = 4 * D, nblk = 8 * m.L;
+  const int dh = m.D / m.H;
+  w.xa = b.take<float>(M * D), w.xb = b.take<float>(M * D), w.h0 = b.take<float>(M * D);
+  w.t1 = b.take<float>(M * D), w.t2 = b.take<float>(M * D), w.t3 = b.take<float>(M * D);
+  w.t4 = b.take<float>(M * D), w.t5 = b.take<float>(M * D);
+  w.qkv = b.take<float>(M * 3 * D);
+  w.phi = b.take<float>(M * 2 * D);
+  w.kvt = b.take<float>((int64_t)B * m.H * dh * dh);
+  w.scr = b.take<float>(M * m.H * (N > 0 ? N : 1));
+  w.f1 = b.take<float>(M * 4 * D);
+  w.hn = b.take<float>(2 * M * D);
+  w.hid = b.take<float>(4 * M * F);
+  w.y2 = b.take<float>(4 * M * D);
+  w.top_idx = b.take<int>(4 * M), w.top_val = b.take<float>(4 * M);
+  w.perm = b.take<int>(4 * M), w.rowscale = b.take<float>(4 * M), w.pos4 = b.take<int>(4 * M);
+  w.hist = b.take<int>(2 * m.E), w.goff = b.take<int>(2 * m.E + 1), w.cursor = b.take<int>(2 * m.E);
+  w.len_low = b.take<int>(B);
+  const int64_t smax = Te > 2 * D ? Te : 2 * D;
+  w.s_a = b.take<float>(B * smax), w.s_b = b.take<float>(B * smax), w.s_c = b.take<float>(B * smax);
+  w.emb = b.take<float>(B * D);
+  w.e1 = b.take<float>(B * nblk * Te);
+  w.sc = b.take<float>(nblk * B * 2 * D);
+  w.gvtmp = b.take<float>(D);
+  const int64_t BN = (int64_t)B * (N > 0 ? N : 1);
+  w.tn = b.take<float>(BN * m.Dt), w.kb = b.take<float>(BN * D), w.vb = b.take<float>(BN * D);
+  w.bytes = (b.off + 255) & ~(int64_t)255;
+  return w;
+}
+
+struct Ctx {
+  const MdmModel* m;
+  hipStream_t s;
+  int prec;
+  int B, S, N;      // batch, frames at this scale, text tokens
+  int64_t M;        // B*S
+  const int* len;   // lengths at this scale
+  Work w;
+};
+
+inline Operand packed(const MdmPacked& p) { return op_bf16(p.hi, p.lo, p.ld); }
+
+// y = epilogue(x @ W^T) for a plain [M,K]x[N,K] Linear
+int linear(const Ctx& c, const float* x, int64_t M, int K, const MdmPacked& W, const float* bias, int N, float* out,
+           int act = ACT_NONE, float alpha = 1.f, float out_scale = 1.f, const float* R1 = nullptr, float r1_scale = 1.f,
+           const float* R2 = nullptr, const float* colscale = nullptr, int r1_mod = 0) {
+  GemmArgs g = gemm_defaults(c.prec);
+  g.A = op_f32(x, K);
+  g.W = packed(W);
+  g.M = (int)M, g.N = N, g.K = K;
+  g.C = out, g.ldc = N;
+  g.bias = bias;
+  g.act = act, g.alpha = alpha, g.out_scale = out_scale;
+  g.R1 = R1, g.ldr1 = N, g.r1_scale = r1_scale, g.r1_mod = r1_mod;
+  g.R2 = R2, g.ldr2 = N;
+  g.colscale = colscale;
+  return gemm(g, c.s);
+}
+
+// out = resid + out_scale * colscale * Lin(SiLU(LN(a)(1+scale)+shift)) with a = [post-processed] src
+int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float* pw, const float* pb, const int* pos4,
+                const float* sc, float* tmp, const float* resid, float out_scale, const float* colscale, float* out) {
+  const int D = c.m->D;
+  MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, tmp, c.s));
+  return linear(c, tmp, c.M, D, st.out, st.out_b, D, out, ACT_NONE, 1.f, out_scale, resid, 1.f, nullptr, colscale);
+}
+
+// PerformerSelfAttention (fast_attention.py:137-179): xn = pre_norm(x) already computed; out = x + 0.1*style(...)
+int performer(const Ctx& c, const MdmPerformer& p, const float* x, const float* xn, const float* sc, float* out) {
+  const MdmModel& m = *c.m;
+  const int D = m.D, H = m.H, dh = D / H, mf = dh;  // m = min(dh, 256) = dh for dh <= 256
+  const Work& w = c.w;
+  // q|k|v = 0.1 * (xn W^T + b)                                   (:145-157)
+  MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, w.qkv, ACT_NONE, 0.1f));
+  // shared LN over head_dim, L2 normalise q,k                     (:44-55)
+  MDM_TRY(head_norm(w.qkv, c.M, H, dh, p.hn_w, p.hn_b, c.s));
+  // feature maps 0.1*exp(clamp(z P)), keys masked past length     (:58-74): rows = (token, slot<2H)
+  {
+    GemmArgs g = gemm_defaults(c.prec);
+    g.A = op_f32(w.qkv, dh);
+    g.A.rpg = 2 * H, g.A.gstride = 3 * D;
+    g.W = packed(p.feat);
+    g.M = (int)(c.M * 2 * H), g.N = mf, g.K = dh;
+    g.C = w.phi, g.ldc = mf;
+    g.act = ACT_FEAT;
+    g.feat_len = c.len, g.feat_S = c.S, g.feat_rpt = 2 * H, g.feat_kslot = H;
+    MDM_TRY(gemm(g, c.s));
+  }
+  // KV^T[b,h] (dh x m) = 0.1 * sum_t v[t] (x) kphi[t]              (:77)
+  {
+    GemmArgs g = gemm_defaults(c.prec);
+    g.A = op_f32_kstride(w.qkv + 2 * D, 3 * D);
+    g.A.bs1 = (int64_t)c.S * 3 * D, g.A.bs2 = dh;
+    g.W = op_f32_kstride(w.phi + H * mf, 2 * H * mf);
+    g.W.bs1 = (int64_t)c.S * 2 * H * mf, g.W.bs2 = mf;
+    g.M = dh, g.N = mf, g.K = c.S;
+    g.batch = c.B * H, g.nb2 = H;
+    g.C = w.kvt, g.ldc = mf, g.c_bs1 = (int64_t)H * dh * mf, g.c_bs2 = (int64_t)dh * mf;
+    g.out_scale = 0.1f;
+    MDM_TRY(gemm(g, c.s));
+  }
+  // num = 0.1 * qphi KV                                            (:78) -> t2 (M, D) merged heads
+  {
+    GemmArgs g = gemm_defaults(c.prec);
+    g.A = op_f32(w.phi, 2 * H * mf);
+    g.A.bs1 = (int64_t)c.S * 2 * H * mf, g.A.bs2 = mf;
+    g.W = op_f32(w.kvt, mf);
+    g.W.bs1 = (int64_t)H * dh * mf, g.W.bs2 = (int64_t)dh * mf;
+    g.M = c.S, g.N = dh, g.K = mf;
+    g.batch = c.B * H, g.nb2 = H;
+    g.C = w.t2, g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
+    g.out_scale = 0.1f;
+    MDM_TRY(gemm(g, c.s));
+  }
+  // same-t denominator, divide, LN over head_dim                   (:81-90) -> t4
+  MDM_TRY(den_ln(w.t2, w.phi, c.M, H, dh, p.hn_w, p.hn_b, w.t4, c.s));
+  // proj_out: Linear -> GELU -> Linear                             (:121-126,165)
+  MDM_TRY(linear(c, w.t4, c.M, D, p.proj0, p.proj0_b, D, w.t2, ACT_GELU));
+  MDM_TRY(linear(c, w.t2, c.M, D, p.proj3, p.proj3_b, D, w.t4));
+  // post_norm, normalize * sqrt(D), stylization, y = x + 0.1 * style (:169-178)
+  return style_apply(c, p.style, w.t4, p.post_w, p.post_b, nullptr, sc, w.t2, x, 0.1f, nullptr, out);
+}
+
+// DualSelfAttentionBlock (fast_attention.py:208-226): x -> out.  Uses t1..t5.
+int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc4, float* out) {
+  const int D = c.m->D;
+  const Work& w = c.w;
+  const int64_t scs = (int64_t)c.B * 2 * D;
+  // h = pre_norm(x) -> t1 ; local.pre_norm(h) -> t3
+  MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, l.local.pre_w, l.local.pre_b, w.t3, c.s));
+  MDM_TRY(performer(c, l.local, w.t1, w.t3, sc4 + 0 * scs, w.t5));  // local_out -> t5
+  MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, nullptr, nullptr, nullptr, c.s));
+  MDM_TRY(performer(c, l.global, w.t5, w.t3, sc4 + 1 * scs, w.t1));  // global_out -> t1
+  // skip = GELU(Lin(x)); out = post_norm(skip + 0.1 * global)      (:219-225)
+  MDM_TRY(linear(c, x, c.M, D, l.skip, l.skip_b, D, w.t3, ACT_GELU, 1.f, 1.f, w.t1, 0.1f));
+  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, nullptr, nullptr, nullptr, c.s);
+}
+
+// GatedCrossAttention (fast_attention.py:242-272): out = x + sigmoid(gate)*sigmoid(adaptive)*style(softmax(q) A)
+int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x, const float* sc, float* out) {
+  const MdmModel& m = *c.m;
+  const int D = m.D, H = m.H, dh = D / H;
+  const Work& w = c.w;
+  MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, nullptr, nullptr, nullptr, c.s));
+  MDM_TRY(linear(c, w.t2, c.M, D, l.ca_q, l.ca_q_b, D, w.t3));
+  MDM_TRY(head_softmax(w.t3, c.M * H, dh, c.s));  // softmax over head_dim (:248)
+  {
+    GemmArgs g = gemm_defaults(c.prec);  // y[b,s,h,:] = q[b,s,h,:] A[b,h]  (:253), W = A^T rows
+    g.A = op_f32(w.t3, D);
+    g.A.bs1 = (int64_t)c.S * D, g.A.bs2 = dh;
+    g.W = op_f32(at, dh);
+    g.W.bs1 = (int64_t)H * dh * dh, g.W.bs2 = (int64_t)dh * dh;
+    g.M = c.S, g.N = dh, g.K = dh;
+    g.batch = c.B * H, g.nb2 = H;
+    g.C = w.t4, g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
+    MDM_TRY(gemm(g, c.s));
+  }
+  return style_apply(c, l.ca_style, w.t4, nullptr, nullptr, nullptr, sc, w.t2, x, 1.f, l.ca_gvec, out);
+}
+
+// MoEMultiBranchFFN (multi_branch.py:52-61) with SwitchMoELayer top-2 routing (switch_moe.py:44-111)
+int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, const int* forced, float* out) {
+  const MdmModel& m = *c.m;
+  const int D = m.D, F = m.F, E = m.E;
+  const Work& w = c.w;
+  MoeGateParams p = {};
+  for (int b = 0; b < 2; ++b) {
+    p.ln_w[b] = l.moe_ln_w[b], p.ln_b[b] = l.moe_ln_b[b];
+    p.gate_w[b] = l.gate_w[b], p.gate_b[b] = l.gate_b[b];
+    p.usage[b] = l.usage[b], p.importance[b] = l.importance[b];
+  }
+  p.hn = w.hn, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.forced_idx = forced;
+  MDM_TRY(moe_route(x, c.M, D, E, p, w.goff, w.cursor, w.perm, w.rowscale, w.pos4, c.s));
+  {
+    GemmArgs g = gemm_defaults(c.prec);  // hidden = GELU(LN_b(x)[routed rows] W1_e^T + b1_e)
+    g.A = op_f32(w.hn, D);
+    g.A.gather = w.perm;
+    g.W = packed(l.w1);
+    g.W.bs1 = (int64_t)F * l.w1.ld;
+    g.goff = w.goff, g.ngroups = 2 * E;
+    g.M = (int)(4 * c.M), g.N = F, g.K = D;
+    g.bias = l.b1, g.bias_bs = F;
+    g.act = ACT_GELU;
+    g.C = w.hid, g.ldc = F;
+    MDM_TRY(gemm(g, c.s));
+  }
+  {
+    GemmArgs g = gemm_defaults(c.prec);  // y2[pos] = prob[pos] * (hidden W2_e^T + b2_e)      (switch_moe.py:108-109)
+    g.A = op_f32(w.hid, F);
+    g.W = packed(l.w2);
+    g.W.bs1 = (int64_t)D * l.w2.ld;
+    g.goff = w.goff, g.ngroups = 2 * E;
+    g.M = (int)(4 * c.M), g.N = D, g.K = F;
+    g.bias = l.b2, g.bias_bs = D;
+    g.rowscale = w.rowscale;
+    g.C = w.y2, g.ldc = D;
+    MDM_TRY(gemm(g, c.s));
+  }
+  // mean of the two branches (each the sum of its two routed rows), stylization, residual
+  return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out);
+}
+
+// MemoryEfficientCrossAttentionBlock (fast_attention.py:301-330); out must not alias x
+int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float* vc, const float* x, float* out) {
+  const MdmModel& m = *c.m;
+  const int D = m.D, H = m.H, dh = D / H, N = c.N;
+  const Work& w = c.w;
+  MDM_TRY(linear(c, x, c.M, D, l.sd_q, l.sd_q_b, D, w.t1, ACT_NONE, 1.f / sqrtf((float)dh)));
+  {
+    GemmArgs g = gemm_defaults(c.prec);  // scores[b,h,s,n] = q . k
+    g.A = op_f32(w.t1, D);
+    g.A.bs1 = (int64_t)c.S * D, g.A.bs2 = dh;
+    g.W = op_f32(kc, D);
+    g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
+    g.M = c.S, g.N = N, g.K = dh;
+    g.batch = c.B * H, g.nb2 = H;
+    g.C = w.scr, g.ldc = N, g.c_bs1 = (int64_t)H * c.S * N, g.c_bs2 = (int64_t)c.S * N;
+    MDM_TRY(gemm(g, c.s));
+  }
+  MDM_TRY(row_softmax(w.scr, c.M * H, N, c.s));
+  {
+    GemmArgs g = gemm_defaults(c.prec);  // o[b,s,h,:] = p v
+    g.A = op_f32(w.scr, N);
+    g.A.bs1 = (int64_t)H * c.S * N, g.A.bs2 = (int64_t)c.S * N;
+    g.W = op_f32_kstride(vc, D);
+    g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
+    g.M = c.S, g.N = dh, g.K = N;
+    g.batch = c.B * H, g.nb2 = H;
+    g.C = w.t2, g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
+    MDM_TRY(gemm(g, c.s));
+  }
+  MDM_TRY(linear(c, w.t2, c.M, D, l.sd_out, l.sd_out_b, D, w.t3));
+  MDM_TRY(ln_chain(w.t3, c.M, D, l.sd_ln_w, l.sd_ln_b, w.t4, nullptr, nullptr, nullptr, c.s));
+  MDM_TRY(linear(c, w.t4, c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, w.f1, ACT_GELU));
+  // x + (o + ffn(o))
+  return linear(c, w.f1, c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, ACT_NONE, 1.f, 1.f, x, 1.f, w.t3);
+}
+
+const float* tc_at(const MdmModel& m, const MdmTextCache& tc, int layer) {
+  const int dh = m.D / m.H;
+  return tc.lin_at + (int64_t)layer * tc.B * m.H * dh * dh;
+}
+const float* tc_k(const MdmModel& m, const MdmTextCache& tc, int layer) {
+  return tc.sd_k + (int64_t)layer * tc.B * tc.N * m.D;
+}
+const float* tc_v(const MdmModel& m, const MdmTextCache& tc, int layer) {
+  return tc.sd_v + (int64_t)layer * tc.B * tc.N * m.D;
+}
+
+// one MoEExtendedDecoderLayer (transformer.py:55-64): x (in xin) -> xout; both are workspace or caller buffers
+int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, const float* xin, float* xmid, float* xout,
+                  const float* sc4, const int* forced, float* trace) {
+  const MdmModel& m = *c.m;
+  const MdmLayer& l = m.layers[layer];
+  const int64_t scs = (int64_t)c.B * 2 * m.D, n = c.M * m.D;
+  auto dump = [&](int slot, const float* p) -> int {
+    if (!trace) return MDM_OK;
+    return hipMemcpyAsync(trace + (int64_t)slot * n, p, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) == hipSuccess
+               ? MDM_OK
+               : MDM_ERR_LAUNCH;
+  };
+  MDM_TRY(dual_block(c, l, xin, sc4, xmid));
+  MDM_TRY(dump(0, xmid));
+  MDM_TRY(cross_block(c, l, tc_at(m, tc, layer), xmid, sc4 + 2 * scs, xout));
+  MDM_TRY(dump(1, xout));
+  MDM_TRY(moe_block(c, l, xout, sc4 + 3 * scs, forced, xmid));
+  MDM_TRY(dump(2, xmid));
+  MDM_TRY(sdcross_block(c, l, tc_k(m, tc, layer), tc_v(m, tc, layer), xmid, xout));
+  return dump(3, xout);
+}
+
+// fused time/text embedding + every stylization block's (scale|shift)  (transformer.py:313-321, stylization.py:22-27)
+int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj, float* emb_out, float* sc_out) {
+  const MdmModel& m = *c.m;
+  const int D = m.D, Te = 4 * D, B = c.B, nblk = 8 * m.L;
+  const Work& w = c.w;
+  MDM_TRY(sinusoid(timesteps, B, D, w.s_a, c.s));
+  MDM_TRY(linear(c, w.s_a, B, D, m.tmlp0, m.tmlp0_b, 2 * D, w.s_b, ACT_SILU));
+  MDM_TRY(linear(c, w.s_b, B, 2 * D, m.tmlp2, m.tmlp2_b, D, w.s_a));
+  MDM_TRY(linear(c, w.s_a, B, D, m.te0, m.te0_b, Te, w.s_b, ACT_SILU));
+  MDM_TRY(linear(c, w.s_b, B, Te, m.te2, m.te2_b, Te, w.s_c));
+  MDM_TRY(linear(c, w.s_c, B, Te, m.tproj, m.tproj_b, D, w.s_a));
+  MDM_TRY(linear(c, w.s_a, B, D, m.gf_time, m.gf_time_b, D, w.s_b));  // t
+  const float* tp = xf_proj;
+  if (m.Dt != D) {  // the per-call random text_proj (transformer.py:313-315), captured
+    if (!m.text_proj.hi) return MDM_ERR_ARG;
+    MDM_TRY(linear(c, xf_proj, B, m.Dt, m.text_proj, m.text_proj_b, D, w.s_c));
+    tp = w.s_c;
+  }
+  MDM_TRY(linear(c, tp, B, D, m.gf_text, m.gf_text_b, D, w.s_a));  // x
+  MDM_TRY(gated_mix(w.s_b, w.s_a, (int64_t)B * D, w.s_c, c.s));
+  MDM_TRY(linear(c, w.s_c, B, D, m.gf_post0, m.gf_post0_b, D, w.s_a, ACT_SILU));
+  float* emb = emb_out ? emb_out : w.emb;
+  MDM_TRY(linear(c, w.s_a, B, D, m.gf_post2, m.gf_post2_b, D, emb));
+  // all 8L blocks at once: e1 = SiLU(emb Weph^T + beph) [B, 8L*Te]; sc[j] = e1[:, j] W1_j^T + b1_j [8L, B, 2D]
+  MDM_TRY(linear(c, emb, B, D, m.style_eph, m.style_eph_b, nblk * Te, w.e1, ACT_SILU));
+  GemmArgs g = gemm_defaults(c.prec);
+  g.A = op_f32(w.e1, (int64_t)nblk * Te);
+  g.A.bs1 = Te;
+  g.W = packed(m.style_emb);
+  g.W.bs1 = (int64_t)2 * D * m.style_emb.ld;
+  g.M = B, g.N = 2 * D, g.K = Te;
+  g.batch = nblk, g.nb2 = 1;
+  g.bias = m.style_emb_b, g.bias_bs = 2 * D;
+  g.C = sc_out, g.ldc = 2 * D, g.c_bs1 = (int64_t)B * 2 * D;
+  return gemm(g, c.s);
+}
+
+int check_model(const MdmModel* m) {
+  if (!m || !m->layers || m->D <= 0 || m->H <= 0 || m->D % m->H || m->L <= 0 || m->E < 2 || m->E > 16) return MDM_ERR_ARG;
+  const int dh = m->D / m->H;
+  if (dh != 16 && dh != 32 && dh != 64 && dh != 128 && dh != 256) return MDM_ERR_UNSUPPORTED;
+  if (m->D > 1024 || m->Dt > 1024 || (m->D & 3) || (m->F & 3)) return MDM_ERR_UNSUPPORTED;
+  return MDM_OK;
+}
+
+}  // namespace
+}  // namespace mdm
+
+using namespace mdm;
+
+extern "C" {
+
+int64_t mdm_workspace_bytes(const MdmModel* m, int32_t B, int32_t T, int32_t N) {
+  if (check_model(m) != MDM_OK || B <= 0 || T <= 0) return -1;
+  return carve(*m, B, T, N, nullptr).bytes;
+}
+
+int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCache* tc, void* ws, int64_t ws_bytes,
+                         int32_t precision, void* stream) {
+  MDM_TRY(check_model(m));
+  if (!xf_out || !tc || !tc->lin_at || !tc->sd_k || !tc->sd_v || tc->B <= 0 || tc->N <= 0 || tc->N > 128 || !ws)
+    return MDM_ERR_ARG;
+  Ctx c = {};
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.B = tc->B, c.N = tc->N;
+  c.w = carve(*m, tc->B, 2, tc->N, ws);
+  if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
+  const int D = m->D, H = m->H, dh = D / H, N = tc->N, B = tc->B;
+  const int64_t BN = (int64_t)B * N;
+  for (int layer = 0; layer < 2 * m->L; ++layer) {
+    const MdmLayer& l = m->layers[layer];
+    MDM_TRY(ln_chain(xf_out, BN, m->Dt, l.ca_tnorm_w, l.ca_tnorm_b, c.w.tn, nullptr, nullptr, nullptr, c.s));
+    MDM_TRY(linear(c, c.w.tn, BN, m->Dt, l.ca_k, l.ca_k_b, D, c.w.kb));
+    MDM_TRY(col_softmax(c.w.kb, B, N, D, c.s));  // softmax over text tokens (fast_attention.py:249)
+    MDM_TRY(linear(c, c.w.tn, BN, m->Dt, l.ca_v, l.ca_v_b, D, c.w.vb));
+    GemmArgs g = gemm_defaults(precision);  // A^T[b,h][l][d] = sum_n v[n,l] k[n,d]   (fast_attention.py:252)
+    g.A = op_f32_kstride(c.w.vb, D);
+    g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
+    g.W = op_f32_kstride(c.w.kb, D);
+    g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
+    g.M = dh, g.N = dh, g.K = N;
+    g.batch = B * H, g.nb2 = H;
+    g.C = (float*)tc_at(*m, *tc, layer), g.ldc = dh, g.c_bs1 = (int64_t)H * dh * dh, g.c_bs2 = (int64_t)dh * dh;
+    MDM_TRY(gemm(g, c.s));
+    MDM_TRY(linear(c, xf_out, BN, m->Dt, l.sd_k, l.sd_k_b, D, (float*)tc_k(*m, *tc, layer)));
+    MDM_TRY(linear(c, xf_out, BN, m->Dt, l.sd_v, l.sd_v_b, D, (float*)tc_v(*m, *tc, layer)));
+  }
+  return MDM_OK;
+}
+
+int mdm_stem_embeddings(const MdmModel* m, const int64_t* timesteps, const float* xf_proj, int32_t B, float* emb_out,
+                        float* sc_out, void* ws, int64_t ws_bytes, int32_t precision, void* stream) {
+  MDM_TRY(check_model(m));
+  if (!timesteps || !xf_proj || !sc_out || !ws || B <= 0) return MDM_ERR_ARG;
+  Ctx c = {};
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.B = B;
+  c.w = carve(*m, B, 2, 1, ws);
+  if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
+  return stem_embeddings(c, timesteps, xf_proj, emb_out, sc_out);
+}
+
+int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float* x, const int64_t* timesteps,
+                         const int32_t* length, const float* xf_proj, int32_t B, int32_t T, float* out, void* ws,
+                         int64_t ws_bytes, const int32_t* forced_routing, float* trace, int32_t precision, void* stream) {
+  MDM_TRY(check_model(m));
+  if (!tc || !x || !timesteps || !length || !xf_proj || !out || !ws || B <= 0 || T <= 0) return MDM_ERR_ARG;
+  if (T % 2 || T > m->num_frames) return MDM_ERR_ARG;  // odd T breaks the U-shape (transformer.py:223-224,353)
+  if (tc->B != B) return MDM_ERR_ARG;
+  Ctx c = {};
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.B = B, c.N = tc->N;
+  c.w = carve(*m, B, T, tc->N, ws);
+  if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
+  const Work& w = c.w;
+  const int D = m->D, L = m->L;
+  const int64_t Mfull = (int64_t)B * T, Mlow = Mfull / 2;
+  const int64_t scl = (int64_t)4 * B * 2 * D;  // (scale|shift) floats per layer
+  MDM_TRY(stem_embeddings(c, timesteps, xf_proj, nullptr, w.sc));
+  // h = joint_embed(x) + sequence_embedding[:T]                     (transformer.py:324-326)
+  MDM_TRY(linear(c, x, Mfull, m->feats, m->joint, m->joint_b, D, w.h0, ACT_NONE, 1.f, 1.f, m->seq_emb, 1.f, nullptr,
+                 nullptr, T));
+  // Conv1d(k=2,s=2) == Linear over pairs of frames                  (:332-337)
+  MDM_TRY(linear(c, w.h0, Mlow, 2 * D, m->down, m->down_b, D, w.xa));
+  MDM_TRY(halve_lengths(length, B, w.len_low, c.s));  // (:341-342)
+  c.S = T / 2, c.M = Mlow, c.len = w.len_low;
+  for (int i = 0; i < L; ++i) {  // coarse scale blocks: xa -> xa (xb = intermediate)   (:343-344)
+    const int32_t* fr = forced_routing ? forced_routing + (int64_t)i * 4 * Mfull : nullptr;
+    float* tr = trace ? trace + (int64_t)i * 4 * Mfull * D : nullptr;
+    MDM_TRY(decoder_layer(c, i, *tc, w.xa, w.xb, w.xa, w.sc + i * scl, fr, tr));
+  }
+  // ConvTranspose1d(k=2,s=2) == Linear D -> 2D per coarse frame, rows (B*T/2, 2D) == (B*T, D); + skip h  (:347-353)
+  MDM_TRY(linear(c, w.xa, Mlow, D, m->up, m->up_b2, 2 * D, w.xb, ACT_NONE, 1.f, 1.f, w.h0));
+  c.S = T, c.M = Mfull, c.len = length;
+  for (int i = 0; i < L; ++i) {  // full scale blocks: xb -> xb                           (:356-357)
+    const int32_t* fr = forced_routing ? forced_routing + (int64_t)(L + i) * 4 * Mfull : nullptr;
+    float* tr = trace ? trace + (int64_t)(L + i) * 4 * Mfull * D : nullptr;
+    MDM_TRY(decoder_layer(c, L + i, *tc, w.xb, w.xa, w.xb, w.sc + (L + i) * scl, fr, tr));
+  }
+  return linear(c, w.xb, Mfull, D, m->out, m->out_b, m->feats, out);  // (:360)
+}
+
+int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const MdmTextCache* tc, const float* h,
+                      const float* sc, const int32_t* len, int32_t B, int32_t S, float* out, void* ws, int64_t ws_bytes,
+                      const int32_t* forced_routing, int32_t precision, void* stream) {
+  MDM_TRY(check_model(m));
+  if (!h || !sc || !len || !out || !ws || B <= 0 || S <= 0 || layer < 0 || layer >= 2 * m->L) return MDM_ERR_ARG;
+  if ((block == MDM_BLOCK_CROSS || block == MDM_BLOCK_SDCROSS || block == MDM_BLOCK_LAYER) && (!tc || tc->B != B))
+    return MDM_ERR_ARG;
+  Ctx c = {};
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.B = B, c.S = S, c.M = (int64_t)B * S, c.len = len;
+  c.N = tc ? tc->N : 1;
+  c.w = carve(*m, B, S, c.N, ws);
+  if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
+  const MdmLayer& l = m->layers[layer];
+  const int64_t scs = (int64_t)B * 2 * m->D;
+  switch (block) {
+    case MDM_BLOCK_DUAL: return dual_block(c, l, h, sc, out);
+    case MDM_BLOCK_CROSS: return cross_block(c, l, tc_at(*m, *tc, layer), h, sc + 2 * scs, out);
+    case MDM_BLOCK_MOE: return moe_block(c, l, h, sc + 3 * scs, forced_routing, out);
+    case MDM_BLOCK_SDCROSS: return sdcross_block(c, l, tc_k(*m, *tc, layer), tc_v(*m, *tc, layer), h, out);
+    case MDM_BLOCK_LAYER: {
+      const int64_t n = c.M * m->D;
+      if (hipMemcpyAsync(c.w.xa, h, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) != hipSuccess) return MDM_ERR_LAUNCH;
+      MDM_TRY(decoder_layer(c, layer, *tc, c.w.xa, c.w.xb, c.w.xa, sc, forced_routing, nullptr));
+      return hipMemcpyAsync(out, c.w.xa, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) == hipSuccess ? MDM_OK
+                                                                                                         : MDM_ERR_LAUNCH;
+    }
+    default: return MDM_ERR_ARG;
+  }
+}
+
+int mdm_stylization_forward(const MdmStyle* st, const float* h, const float* sc, int32_t B, int32_t S, int32_t D,
+                            float* tmp, float* out, int32_t precision, void* stream) {
+  if (!st || !h || !sc || !tmp || !out || B <= 0 || S <= 0) return MDM_ERR_ARG;
+  MdmModel fake = {};
+  fake.D = D;
+  Ctx c = {};
+  c.m = &fake, c.s = (hipStream_t)stream, c.prec = precision, c.B = B, c.S = S, c.M = (int64_t)B * S;
+  return style_apply(c, *st, h, nullptr, nullptr, nullptr, sc, tmp, nullptr, 1.f, nullptr, out);
+}
+
+int mdm_cfg_posterior_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n,
+                           const float* tab, int32_t steps, const int32_t* t_dev, int32_t t_imm, float cfg_scale,
+                           float* x_out, float* x0_out, void* stream) {
+  if (steps <= 0 || (!t_dev && (t_imm < 0 || t_imm >= steps))) return MDM_ERR_ARG;
+  return cfg_step(x, eps_c, eps_u, noise, n, tab, steps, t_dev, t_imm, cfg_scale, x_out, x0_out, (hipStream_t)stream);
+}
+
+int mdm_ddim_step(const float* x, const float* eps, const float* noise, int64_t n, const float* tab, int32_t steps,
+                  const int32_t* t_dev, int32_t t_imm, float eta, int32_t clip_denoised, float* x_out, float* x0_out,
+                  void* stream) {
+  if (steps <= 0 || (!t_dev && (t_imm < 0 || t_imm >= steps))) return MDM_ERR_ARG;
+  return ddim_step(x, eps, noise, n, tab, steps, t_dev, t_imm, eta, clip_denoised, x_out, x0_out, (hipStream_t)stream);
+}
+
+int mdm_xattn_gate(const float* gate, const float* adaptive_gate, int32_t D, float* out, void* stream) {
+  if (!gate || !adaptive_gate || !out || D <= 0) return MDM_ERR_ARG;
+  return xattn_gate(gate, adaptive_gate, D, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,628 @@
+// Row-wise (HBM-bound) kernels of the denoiser: LayerNorm chains, stylization inputs, per-head
+// normalisations of the Performer attention, softmaxes, MoE routing and the sampler update.
+// One wave (64 lanes) owns one row of D elements; everything stays in fp32.
+#include "kernels.h"
+
+namespace mdm {
+namespace {
+
+constexpr int WPB = 4;  // waves (rows) per 256-thread block
+
+// ---- a row of D floats spread over a wave ------------------------------------------------------
+// VEC: D == 4*64*NV4 exactly, lane holds NV4 float4 (coalesced 16 B/lane); else generic strided scalars.
+template <int NE, bool VEC>
+struct Row {
+  float e[NE];
+  __device__ __forceinline__ void load(const float* __restrict__ p, int D, int lane) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c) {
+        f32x4 v = *(const f32x4*)(p + 4 * (lane + 64 * c));
+        e[4 * c + 0] = v[0], e[4 * c + 1] = v[1], e[4 * c + 2] = v[2], e[4 * c + 3] = v[3];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int i = lane + 64 * j;
+        e[j] = i < D ? p[i] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ p, int D, int lane) const {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c) {
+        f32x4 v = {e[4 * c + 0], e[4 * c + 1], e[4 * c + 2], e[4 * c + 3]};
+        *(f32x4*)(p + 4 * (lane + 64 * c)) = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int i = lane + 64 * j;
+        if (i < D) p[i] = e[j];
+      }
+    }
+  }
+  __device__ __forceinline__ float sum() const {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) s += e[j];
+    return wave_sum(s);
+  }
+  // LayerNorm in place (eps 1e-5, biased variance, two-pass like ATen); padded lanes stay 0
+  __device__ __forceinline__ void layernorm(const float* __restrict__ w, const float* __restrict__ b, int D, int lane) {
+    const float mean = sum() / D;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const bool in = VEC || (lane + 64 * j < D);
+      const float d = in ? e[j] - mean : 0.f;
+      s += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(s) / D + 1e-5f);
+    Row<NE, VEC> ww, bb;
+    ww.load(w, D, lane);
+    bb.load(b, D, lane);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const bool in = VEC || (lane + 64 * j < D);
+      e[j] = in ? (e[j] - mean) * rstd * ww.e[j] + bb.e[j] : 0.f;
+    }
+  }
+};
+
+#define MDM_ROW_DISPATCH(D, CALL)                      \
+  do {                                                 \
+    if ((D) == 512) {                                  \
+      CALL(8, true);                                   \
+    } else if ((D) == 1024) {                          \
+      CALL(16, true);                                  \
+    } else if ((D) == 256) {                           \
+      CALL(4, true);                                   \
+    } else if ((D) <= 256) {                           \
+      CALL(4, false);                                  \
+    } else if ((D) <= 1024) {                          \
+      CALL(16, false);                                 \
+    } else {                                           \
+      return MDM_ERR_UNSUPPORTED;                      \
+    }                                                  \
+  } while (0)
+
+// ---- LN chain: y1 = LN1(x), y2 = LN2(y1) --------------------------------------------------------
+template <int NE, bool VEC>
+__global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, int64_t M, int D,
+                                                       const float* w1, const float* b1, float* y1,
+                                                       const float* w2, const float* b2, float* y2) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
+    Row<NE, VEC> r;
+    r.load(x + row * D, D, lane);
+    r.layernorm(w1, b1, D, lane);
+    if (y1) r.store(y1 + row * D, D, lane);
+    if (w2) {
+      r.layernorm(w2, b2, D, lane);
+      r.store(y2 + row * D, D, lane);
+    }
+  }
+}
+
+// ---- stylization input: s = SiLU( LN_style(a) * (1 + scale[b]) + shift[b] ) ---------------------
+// a = x                                               (cross / ffn blocks, stylization.py:29-30)
+// a = normalize(LN_post(x)) * sqrt(D)                  (Performer tail, fast_attention.py:169-172)
+// a = 0.5 * sum of the 4 routed expert rows            (MoE combine, switch_moe.py:109 + multi_branch.py:58-59)
+template <int NE, bool VEC>
+__global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__ x, int64_t M, int D, int S,
+                                                       const float* pw, const float* pb,  // optional post_norm
+                                                       const float* sw, const float* sb,  // style norm
+                                                       const float* __restrict__ sc,      // (B, 2D) scale|shift
+                                                       const int* __restrict__ pos4,      // optional (M,4) rows of y2
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
+    Row<NE, VEC> r;
+    if (pos4) {
+      Row<NE, VEC> a, b, c, d;
+      a.load(x + (int64_t)pos4[row * 4 + 0] * D, D, lane);
+      b.load(x + (int64_t)pos4[row * 4 + 1] * D, D, lane);
+      c.load(x + (int64_t)pos4[row * 4 + 2] * D, D, lane);
+      d.load(x + (int64_t)pos4[row * 4 + 3] * D, D, lane);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) r.e[j] = ((a.e[j] + b.e[j]) + (c.e[j] + d.e[j])) * 0.5f;
+    } else {
+      r.load(x + row * D, D, lane);
+    }
+    if (pw) {
+      r.layernorm(pw, pb, D, lane);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NE; ++j) s += r.e[j] * r.e[j];
+      const float inv = sqrtf((float)D) / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) r.e[j] *= inv;
+    }
+    r.layernorm(sw, sb, D, lane);
+    const float* scb = sc + (row / S) * 2 * (int64_t)D;
+    Row<NE, VEC> scale, shift;
+    scale.load(scb, D, lane);
+    shift.load(scb + D, D, lane);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) r.e[j] = silu(r.e[j] * (1.f + scale.e[j]) + shift.e[j]);
+    r.store(out + row * D, D, lane);
+  }
+}
+
+// ---- MoE router: both branches' LayerNorm + gate + softmax + top-2 (lowest index wins ties) -----
+template <int NE, bool VEC>
+__global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__ x, int64_t M, int D, int E,
+                                                       MoeGateParams p) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
+    Row<NE, VEC> xr;
+    xr.load(x + row * D, D, lane);
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+      Row<NE, VEC> r = xr;
+      r.layernorm(p.ln_w[br], p.ln_b[br], D, lane);
+      r.store(p.hn + ((int64_t)br * M + row) * D, D, lane);
+      float logit[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        logit[e] = -INFINITY;
+        if (e < E) {
+          Row<NE, VEC> g;
+          g.load(p.gate_w[br] + (int64_t)e * D, D, lane);
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < NE; ++j) s += r.e[j] * g.e[j];
+          logit[e] = wave_sum(s) + p.gate_b[br][e];
+          mx = fmaxf(mx, logit[e]);
+        }
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        logit[e] = e < E ? expf(logit[e] - mx) : 0.f;
+        den += logit[e];
+      }
+      int i1 = 0, i2 = -1;
+      float v1 = -1.f, v2 = -1.f;
+      if (p.forced_idx) {  // test hook: routing injected, probabilities still computed here
+        i1 = p.forced_idx[((int64_t)br * M + row) * 2 + 0];
+        i2 = p.forced_idx[((int64_t)br * M + row) * 2 + 1];
+        v1 = v2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = logit[e] / den;
+          v1 = e == i1 ? pe : v1;
+          v2 = e == i2 ? pe : v2;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = logit[e] / den;
+          if (e < E) {
+            if (pe > v1) {
+              v2 = v1, i2 = i1;
+              v1 = pe, i1 = e;
+            } else if (pe > v2) {
+              v2 = pe, i2 = e;
+            }
+          }
+        }
+      }
+      if (lane == 0) {
+        const int64_t o = ((int64_t)br * M + row) * 2;
+        p.top_idx[o] = i1, p.top_idx[o + 1] = i2;
+        p.top_val[o] = v1, p.top_val[o + 1] = v2;
+        atomicAdd(&p.hist[br * E + i1], 1);
+        atomicAdd(&p.hist[br * E + i2], 1);
+        if (p.usage[br]) {  // switch_moe.py:71-92 counters, device side, no host sync
+          atomicAdd(&p.usage[br][i1], 1.f);
+          atomicAdd(&p.importance[br][i1], v1);
+          atomicAdd(&p.importance[br][i2], v2);
+        }
+      }
+    }
+  }
+}
+
+__global__ void moe_offsets_kernel(const int* __restrict__ hist, int G, int* __restrict__ goff, int* __restrict__ cursor) {
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int g = 0; g < G; ++g) {
+      goff[g] = s;
+      cursor[g] = 0;
+      s += hist[g];
+    }
+    goff[G] = s;
+  }
+}
+
+__global__ void moe_assign_kernel(const int* __restrict__ top_idx, const float* __restrict__ top_val, int64_t M, int E,
+                                  const int* __restrict__ goff, int* __restrict__ cursor, int* __restrict__ perm,
+                                  float* __restrict__ rowscale, int* __restrict__ pos4) {
+  const int64_t total = 2 * M * 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t br = i / (2 * M), rem = i - br * 2 * M, tok = rem >> 1;
+    const int k = (int)(rem & 1);
+    const int g = (int)br * E + top_idx[i];
+    const int pos = goff[g] + atomicAdd(&cursor[g], 1);
+    perm[pos] = (int)(br * M + tok);
+    rowscale[pos] = top_val[i];
+    pos4[tok * 4 + br * 2 + k] = pos;
+  }
+}
+
+// ---- per-head (dh) units: G lanes x 4 floats -----------------------------------------------------
+template <int G>
+__device__ __forceinline__ void head_ln(f32x4& v, const float* w, const float* b, int dh, int gl) {
+  const float mean = group_sum<G>(v[0] + v[1] + v[2] + v[3]) / dh;
+  const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+  const float rstd = rsqrtf(group_sum<G>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) / dh + 1e-5f);
+  const f32x4 ww = *(const f32x4*)(w + 4 * gl), bb = *(const f32x4*)(b + 4 * gl);
+  v = (f32x4){d[0] * rstd * ww[0] + bb[0], d[1] * rstd * ww[1] + bb[1], d[2] * rstd * ww[2] + bb[2],
+              d[3] * rstd * ww[3] + bb[3]};
+}
+
+// qkv (M,3,H,dh) in place: LN_dh on q,k,v; L2-normalise q,k           (fast_attention.py:44-55)
+template <int G>
+__global__ __launch_bounds__(256) void head_norm_kernel(float* __restrict__ qkv, int64_t units, int H, int dh,
+                                                        const float* w, const float* b) {
+  const int gl = threadIdx.x % G;
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int64_t ng = (int64_t)gridDim.x * blockDim.x / G;
+  for (int64_t u = gid; u < units; u += ng) {
+    float* p = qkv + u * dh + 4 * gl;
+    f32x4 v = *(const f32x4*)p;
+    head_ln<G>(v, w, b, dh, gl);
+    const int which = (int)((u / H) % 3);
+    if (which < 2) {
+      const float n = sqrtf(group_sum<G>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+      const float inv = 1.f / fmaxf(n, 1e-12f);
+      v *= inv;
+    }
+    *(f32x4*)p = v;
+  }
+}
+
+// out[tok,h,:] = LN_dh( num[tok,h,:] / max(<qphi,kphi>, 1e-6) )       (fast_attention.py:81-90); m == dh
+template <int G>
+__global__ __launch_bounds__(256) void den_ln_kernel(const float* __restrict__ num, const float* __restrict__ phi,
+                                                     int64_t M, int H, int dh, const float* w, const float* b,
+                                                     float* __restrict__ out) {
+  const int gl = threadIdx.x % G;
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int64_t ng = (int64_t)gridDim.x * blockDim.x / G;
+  for (int64_t u = gid; u < M * H; u += ng) {
+    const int64_t tok = u / H, h = u - tok * H;
+    const f32x4 qf = *(const f32x4*)(phi + (tok * 2 * H + h) * dh + 4 * gl);
+    const f32x4 kf = *(const f32x4*)(phi + (tok * 2 * H + H + h) * dh + 4 * gl);
+    float den = group_sum<G>(qf[0] * kf[0] + qf[1] * kf[1] + qf[2] * kf[2] + qf[3] * kf[3]);
+    den = fmaxf(den, 1e-6f);
+    f32x4 v = *(const f32x4*)(num + u * dh + 4 * gl);
+    v = (f32x4){v[0] / den, v[1] / den, v[2] / den, v[3] / den};
+    head_ln<G>(v, w, b, dh, gl);
+    *(f32x4*)(out + u * dh + 4 * gl) = v;
+  }
+}
+
+// softmax over dh per (token, head), in place                           (fast_attention.py:248)
+template <int G>
+__global__ __launch_bounds__(256) void head_softmax_kernel(float* __restrict__ q, int64_t units, int dh) {
+  const int gl = threadIdx.x % G;
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int64_t ng = (int64_t)gridDim.x * blockDim.x / G;
+  for (int64_t u = gid; u < units; u += ng) {
+    float* p = q + u * dh + 4 * gl;
+    f32x4 v = *(const f32x4*)p;
+    const float mx = group_max<G>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+    v = (f32x4){expf(v[0] - mx), expf(v[1] - mx), expf(v[2] - mx), expf(v[3] - mx)};
+    const float s = group_sum<G>(v[0] + v[1] + v[2] + v[3]);
+    *(f32x4*)p = (f32x4){v[0] / s, v[1] / s, v[2] / s, v[3] / s};
+  }
+}
+
+#define MDM_HEAD_DISPATCH(dh, CALL)                 \
+  do {                                              \
+    switch (dh) {                                   \
+      case 16: CALL(4); break;                      \
+      case 32: CALL(8); break;                      \
+      case 64: CALL(16); break;                     \
+      case 128: CALL(32); break;                    \
+      case 256: CALL(64); break;                    \
+      default: return MDM_ERR_UNSUPPORTED;          \
+    }                                               \
+  } while (0)
+
+// softmax over the last dim N <= 128 of a (rows, N) matrix, 32 lanes per row, in place (fast_attention.py:320)
+__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ s, int64_t rows, int N) {
+  const int gl = threadIdx.x & 31;
+  const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 5;
+  const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 5;
+  for (int64_t r = gid; r < rows; r += ng) {
+    float* p = s + r * N;
+    float v[4], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = gl + 32 * j;
+      v[j] = i < N ? p[i] : -INFINITY;
+      mx = fmaxf(mx, v[j]);
+    }
+    mx = group_max<32>(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (gl + 32 * j < N) ? expf(v[j] - mx) : 0.f;
+      sum += v[j];
+    }
+    sum = group_sum<32>(sum);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (gl + 32 * j < N) p[gl + 32 * j] = v[j] / sum;
+  }
+}
+
+// softmax over the token axis n of k (B,N,D), one thread per (b, column), in place (fast_attention.py:249)
+__global__ void col_softmax_kernel(float* __restrict__ k, int B, int N, int D) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * D) return;
+  const int64_t b = i / D, c = i - b * D;
+  float* p = k + b * N * (int64_t)D + c;
+  float mx = -INFINITY;
+  for (int n = 0; n < N; ++n) mx = fmaxf(mx, p[(int64_t)n * D]);
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += expf(p[(int64_t)n * D] - mx);
+  for (int n = 0; n < N; ++n) p[(int64_t)n * D] = expf(p[(int64_t)n * D] - mx) / s;
+}
+
+// ---- stem pieces ---------------------------------------------------------------------------------
+// time.py:15-27: emb[b, i] = cos(t_b * f_i), emb[b, half + i] = sin(t_b * f_i), f_i = exp(-ln(1e4) * i / half)
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, int B, int D, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = D / 2;
+  if (i >= B * D) return;
+  const int b = i / D, c = i - b * D;
+  float v = 0.f;
+  if (c < 2 * half) {
+    const int f = c < half ? c : c - half;
+    const float freq = expf(-9.210340371976184f * (float)f / (float)half);
+    const float arg = (float)t[b] * freq;
+    v = c < half ? cosf(arg) : sinf(arg);
+  }
+  out[i] = v;
+}
+
+// gate.py:18-20: g = sigmoid(t + x); out = g * t + (1 - g) * x
+__global__ void gated_mix_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t n,
+                                 float* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float tv = t[i], xv = x[i];
+  const float g = 1.f / (1.f + expf(-(tv + xv)));
+  out[i] = g * tv + (1.f - g) * xv;
+}
+
+// gate vector of the gated cross attention: gvec[c] = sigmoid(gate[c]) * sigmoid(adaptive_gate)
+// (fast_attention.py:256-257,271-272 folded: x + sg*(x + sa*style - x) = x + sg*sa*style)
+__global__ void xattn_gate_kernel(const float* __restrict__ gate, const float* __restrict__ ag, int D,
+                                  float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D) out[i] = (1.f / (1.f + expf(-gate[i]))) * (1.f / (1.f + expf(-ag[0])));
+}
+
+__global__ void halve_lengths_kernel(const int* __restrict__ len, int B, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = (int)(((float)len[i]) / 2.f);  // (length / 2).long(), transformer.py:341
+}
+
+// ---- sampler updates (gaussian_diffusion.py:554-558, 462-475, 1075-1096, 725-742) ---------------
+__global__ void cfg_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+                                const float* __restrict__ eps_u, const float* __restrict__ noise, int64_t n,
+                                const float* __restrict__ tab, int ts, const int* __restrict__ t_ptr, int t_imm, float cfg_scale,
+                                float* __restrict__ x_out, float* __restrict__ x0_out) {
+  const int t = t_ptr ? *t_ptr : t_imm;
+  const float a = tab[TAB_SQRT_RECIP * ts + t], b = tab[TAB_SQRT_RECIPM1 * ts + t];
+  const float c1 = tab[TAB_COEF1 * ts + t], c2 = tab[TAB_COEF2 * ts + t];
+  const float sd = t == 0 ? 0.f : expf(0.5f * tab[TAB_LOGVAR * ts + t]);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = x[i];
+    const float x0c = a * xv - b * eps_c[i];
+    float x0 = x0c;
+    if (eps_u) {
+      const float x0u = a * xv - b * eps_u[i];
+      x0 = x0u + cfg_scale * (x0c - x0u);
+    }
+    const float mean = c1 * x0 + c2 * xv;
+    x_out[i] = mean + (noise ? sd * noise[i] : 0.f);
+    if (x0_out) x0_out[i] = x0;
+  }
+}
+
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_in,
+                                 const float* __restrict__ noise, int64_t n, const float* __restrict__ tab, int ts,
+                                 const int* __restrict__ t_ptr, int t_imm, float eta, int clip,
+                                 float* __restrict__ x_out, float* __restrict__ x0_out) {
+  const int t = t_ptr ? *t_ptr : t_imm;
+  const float a = tab[TAB_SQRT_RECIP * ts + t], b = tab[TAB_SQRT_RECIPM1 * ts + t];
+  const float ab = tab[TAB_ACP * ts + t], abp = tab[TAB_ACP_PREV * ts + t];
+  const float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+  const float sq_abp = sqrtf(abp), dir = sqrtf(1.f - abp - sigma * sigma);
+  const float nz = t == 0 ? 0.f : 1.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = x[i];
+    float x0 = a * xv - b * eps_in[i];
+    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    const float eps = (a * xv - x0) / b;
+    const float mean = x0 * sq_abp + dir * eps;
+    x_out[i] = mean + (noise ? nz * sigma * noise[i] : 0.f);
+    if (x0_out) x0_out[i] = x0;
+  }
+}
+
+__global__ void fill_i64_kernel(int64_t* dst, int64_t n, const int* src) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (int64_t)*src;
+}
+__global__ void add_i32_kernel(int* dst, int delta) { *dst += delta; }
+
+inline int row_grid(int64_t M) {
+  int64_t g = (M + WPB - 1) / WPB;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+inline int unit_grid(int64_t units, int G) {
+  int64_t per_block = 256 / G;
+  int64_t g = (units + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, float* y1, const float* w2,
+             const float* b2, float* y2, hipStream_t s) {
+  if (M <= 0) return MDM_OK;
+  if (!x || !w1 || !b1 || (w2 && (!b2 || !y2)) || (!w2 && !y1)) return MDM_ERR_ARG;
+#define CALL(NE, VEC) \
+  hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, w1, b1, y1, w2, b2, y2)
+  MDM_ROW_DISPATCH(D, CALL);
+#undef CALL
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int style_in(const float* x, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw,
+             const float* sb, const float* sc, const int* pos4, float* out, hipStream_t s) {
+  if (M <= 0) return MDM_OK;
+  if (!x || !sw || !sb || !sc || !out || S <= 0) return MDM_ERR_ARG;
+#define CALL(NE, VEC)                                                                                              \
+  hipLaunchKernelGGL((style_in_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, S, pw, pb, sw, sb, sc, \
+                     pos4, out)
+  MDM_ROW_DISPATCH(D, CALL);
+#undef CALL
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, int* goff, int* cursor, int* perm,
+              float* rowscale, int* pos4, hipStream_t s) {
+  if (M <= 0) return MDM_OK;
+  if (E < 2 || E > 16 || !x || !p.hn || !p.hist || !p.top_idx || !p.top_val) return MDM_ERR_ARG;
+  if (hipMemsetAsync(p.hist, 0, sizeof(int) * 2 * E, s) != hipSuccess) return MDM_ERR_LAUNCH;
+#define CALL(NE, VEC) hipLaunchKernelGGL((moe_gate_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, E, p)
+  MDM_ROW_DISPATCH(D, CALL);
+#undef CALL
+  hipLaunchKernelGGL(moe_offsets_kernel, dim3(1), dim3(64), 0, s, p.hist, 2 * E, goff, cursor);
+  const int64_t total = 4 * M;
+  int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(moe_assign_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, p.top_idx, p.top_val, M, E,
+                     goff, cursor, perm, rowscale, pos4);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int head_norm(float* qkv, int64_t M, int H, int dh, const float* w, const float* b, hipStream_t s) {
+  if (M <= 0) return MDM_OK;
+  const int64_t units = M * 3 * H;
+#define CALL(G) hipLaunchKernelGGL((head_norm_kernel<G>), dim3(unit_grid(units, G)), dim3(256), 0, s, qkv, units, H, dh, w, b)
+  MDM_HEAD_DISPATCH(dh, CALL);
+#undef CALL
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const float* w, const float* b, float* out,
+           hipStream_t s) {
+  if (M <= 0) return MDM_OK;
+#define CALL(G) \
+  hipLaunchKernelGGL((den_ln_kernel<G>), dim3(unit_grid(M * H, G)), dim3(256), 0, s, num, phi, M, H, dh, w, b, out)
+  MDM_HEAD_DISPATCH(dh, CALL);
+#undef CALL
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int head_softmax(float* q, int64_t units, int dh, hipStream_t s) {
+  if (units <= 0) return MDM_OK;
+#define CALL(G) hipLaunchKernelGGL((head_softmax_kernel<G>), dim3(unit_grid(units, G)), dim3(256), 0, s, q, units, dh)
+  MDM_HEAD_DISPATCH(dh, CALL);
+#undef CALL
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int row_softmax(float* sc, int64_t rows, int N, hipStream_t s) {
+  if (rows <= 0) return MDM_OK;
+  if (N < 1 || N > 128) return MDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(row_softmax_kernel, dim3(unit_grid(rows, 32)), dim3(256), 0, s, sc, rows, N);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int col_softmax(float* k, int B, int N, int D, hipStream_t s) {
+  const int64_t n = (int64_t)B * D;
+  if (n <= 0) return MDM_OK;
+  hipLaunchKernelGGL(col_softmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, B, N, D);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(sinusoid_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, t, B, D, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(gated_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, x, n, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int xattn_gate(const float* gate, const float* ag, int D, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(xattn_gate_kernel, dim3((D + 255) / 256), dim3(256), 0, s, gate, ag, D, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int halve_lengths(const int* len, int B, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(halve_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, s, len, B, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int fill_i64(int64_t* dst, int64_t n, const int* src, hipStream_t s) {
+  if (n <= 0) return MDM_OK;
+  hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, src);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int add_i32(int* dst, int delta, hipStream_t s) {
+  hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, s, dst, delta);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int cfg_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n, const float* tab,
+             int ts, const int* t_ptr, int t_imm, float cfg_scale, float* x_out, float* x0_out, hipStream_t s) {
+  if (n <= 0) return MDM_OK;
+  if (!x || !eps_c || !tab || !x_out) return MDM_ERR_ARG;
+  int blocks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(cfg_step_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, s, x, eps_c, eps_u, noise, n,
+                     tab, ts, t_ptr, t_imm, cfg_scale, x_out, x0_out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int ddim_step(const float* x, const float* eps, const float* noise, int64_t n, const float* tab, int ts, const int* t_ptr,
+              int t_imm, float eta, int clip, float* x_out, float* x0_out, hipStream_t s) {
+  if (n <= 0) return MDM_OK;
+  if (!x || !eps || !tab || !x_out) return MDM_ERR_ARG;
+  int blocks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, s, x, eps, noise, n, tab, ts,
+                     t_ptr, t_imm, eta, clip, x_out, x0_out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+}  // namespace mdm

@@ -1,0 +1,208 @@
+"""Weight packing: reference ``state_dict`` layout -> kernel layouts -> ``MdmModel`` (include/mdm_hip.h).
+
+Two stages so the layout logic is checkable without a GPU:
+  * ``kernel_layout(sd, cfg, eph, proj)``: pure tensor reshapes/concats (fp32, any device);
+  * ``PackedModel(...)``: uploads, splits every matrix into bf16 hi/lo planes with the HIP pack kernel and
+    fills the ctypes structs.  Runs once per (weights, captured randomness), never on the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import _lib as L
+from .synth import ephemeral_names, projection_names
+
+STYLE_SLOTS = ("local_style", "global_style", "cross_style", "ffn_style")
+
+
+def layer_tags(num_layers: int) -> List[Tuple[str, str]]:
+    """(state_dict prefix, captured-randomness tag) for the 2L decoder layers: low blocks then high blocks."""
+    out = []
+    for scale in ("low", "high"):
+        for i in range(num_layers):
+            out.append((f"decoder_blocks_{scale}.{i}.module", f"{scale}.{i}"))
+    return out
+
+
+def kernel_layout(sd: Dict[str, torch.Tensor], cfg: dict, eph: Dict[str, Tuple[torch.Tensor, torch.Tensor]],
+                  proj: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Matrices ("W:" keys, [N,K] fp32) and vectors ("V:" keys) in the layouts the kernels read."""
+    D, L_, E = cfg["latent_dim"], cfg["num_layers"], cfg["moe_num_experts"]
+    out: Dict[str, torch.Tensor] = {}
+
+    def lin(dst, src):
+        out["W:" + dst] = sd[src + ".weight"]
+        out["V:" + dst + "_b"] = sd[src + ".bias"]
+
+    lin("tmlp0", "learnable_time_embed.mlp.0"), lin("tmlp2", "learnable_time_embed.mlp.2")
+    lin("te0", "time_embed.0"), lin("te2", "time_embed.2"), lin("tproj", "time_proj")
+    lin("gf_time", "gated_fusion.proj_time"), lin("gf_text", "gated_fusion.proj_text")
+    lin("gf_post0", "gated_fusion.post_mlp.0"), lin("gf_post2", "gated_fusion.post_mlp.2")
+    lin("joint", "joint_embed"), lin("out", "out")
+    if "text_proj" in eph:
+        out["W:text_proj"], out["V:text_proj_b"] = eph["text_proj"]
+    # Conv1d(k=2,s=2) weight (out,in,k) -> [out, k*D + in]: a Linear over the concatenated frame pair (transformer.py:223,334)
+    out["W:down"] = sd["downsample.weight"].permute(0, 2, 1).reshape(D, 2 * D)
+    out["V:down_b"] = sd["downsample.bias"]
+    # ConvTranspose1d(k=2,s=2) weight (in,out,k) -> [k*D + out, in]: each coarse frame emits its two fine frames (:224,348)
+    out["W:up"] = sd["upsample.weight"].permute(2, 1, 0).reshape(2 * D, D)
+    out["V:up_b2"] = torch.cat([sd["upsample.bias"], sd["upsample.bias"]])
+    out["V:seq_emb"] = sd["sequence_embedding"]
+    eph_w, eph_b, emb_w, emb_b = [], [], [], []
+    for li, (pre, tag) in enumerate(layer_tags(L_)):
+        k = f"L{li}."
+        d = pre + ".dual_self_attn"
+        for nm in ("pre_norm", "post_norm"):
+            out[f"V:{k}dual_{nm}_w"], out[f"V:{k}dual_{nm}_b"] = sd[f"{d}.{nm}.weight"], sd[f"{d}.{nm}.bias"]
+        for which in ("local", "global"):
+            a = f"{d}.{which}_attn"
+            q = k + which + "."
+            for nm in ("pre_norm", "post_norm"):
+                out[f"V:{q}{nm}_w"], out[f"V:{q}{nm}_b"] = sd[f"{a}.{nm}.weight"], sd[f"{a}.{nm}.bias"]
+            out["W:" + q + "qkv"] = torch.cat([sd[a + ".query.weight"], sd[a + ".key.weight"], sd[a + ".value.weight"]], 0)
+            out["V:" + q + "qkv_b"] = torch.cat([sd[a + ".query.bias"], sd[a + ".key.bias"], sd[a + ".value.bias"]])
+            out["V:" + q + "hn_w"], out["V:" + q + "hn_b"] = sd[a + ".fast_attention.norm.weight"], sd[a + ".fast_attention.norm.bias"]
+            out["W:" + q + "feat"] = proj[f"{tag}.{which}"].t()  # [m, dh]
+            out["W:" + q + "proj0"], out["V:" + q + "proj0_b"] = sd[a + ".proj_out.0.weight"], sd[a + ".proj_out.0.bias"]
+            out["W:" + q + "proj3"], out["V:" + q + "proj3_b"] = sd[a + ".proj_out.3.weight"], sd[a + ".proj_out.3.bias"]
+            _style(out, sd, q + "style.", a + ".style_block")
+            emb_w.append(sd[a + ".style_block.emb_layers.1.weight"]), emb_b.append(sd[a + ".style_block.emb_layers.1.bias"])
+        out["W:" + k + "skip"], out["V:" + k + "skip_b"] = sd[d + ".skip_proj.0.weight"], sd[d + ".skip_proj.0.bias"]
+        c = pre + ".cross_attn.base_ca"
+        out[f"V:{k}ca_norm_w"], out[f"V:{k}ca_norm_b"] = sd[c + ".norm.weight"], sd[c + ".norm.bias"]
+        out[f"V:{k}ca_tnorm_w"], out[f"V:{k}ca_tnorm_b"] = sd[c + ".text_norm.weight"], sd[c + ".text_norm.bias"]
+        for nm, src in (("ca_q", "query"), ("ca_k", "key"), ("ca_v", "value")):
+            out["W:" + k + nm], out["V:" + k + nm + "_b"] = sd[f"{c}.{src}.weight"], sd[f"{c}.{src}.bias"]
+        out["V:" + k + "ca_gate"] = sd[pre + ".cross_attn.gate"]
+        out["V:" + k + "ca_adaptive"] = sd[c + ".adaptive_gate"]
+        _style(out, sd, k + "ca_style.", c + ".proj_out")
+        emb_w.append(sd[c + ".proj_out.emb_layers.1.weight"]), emb_b.append(sd[c + ".proj_out.emb_layers.1.bias"])
+        f = pre + ".ffn"
+        w1, b1, w2, b2 = [], [], [], []
+        for b in range(2):
+            br = f"{f}.branches.{b}"
+            out[f"V:{k}moe_ln_w{b}"], out[f"V:{k}moe_ln_b{b}"] = sd[br + ".layernorm.weight"], sd[br + ".layernorm.bias"]
+            out[f"V:{k}gate_w{b}"], out[f"V:{k}gate_b{b}"] = sd[br + ".moe.gate.weight"], sd[br + ".moe.gate.bias"]
+            for e in range(E):
+                w1.append(sd[f"{br}.moe.experts.{e}.0.weight"]), b1.append(sd[f"{br}.moe.experts.{e}.0.bias"])
+                w2.append(sd[f"{br}.moe.experts.{e}.2.weight"]), b2.append(sd[f"{br}.moe.experts.{e}.2.bias"])
+        out["W:" + k + "w1"], out["V:" + k + "b1"] = torch.cat(w1, 0), torch.cat(b1)  # [2*E*F, D]
+        out["W:" + k + "w2"], out["V:" + k + "b2"] = torch.cat(w2, 0), torch.cat(b2)  # [2*E*D, F]
+        _style(out, sd, k + "ffn_style.", f + ".proj_out")
+        emb_w.append(sd[f + ".proj_out.emb_layers.1.weight"]), emb_b.append(sd[f + ".proj_out.emb_layers.1.bias"])
+        s = pre + ".sd_cross_attn"
+        for nm, src in (("sd_q", "query"), ("sd_k", "key"), ("sd_v", "value"), ("sd_out", "out"), ("sd_f1", "ffn.1"),
+                        ("sd_f2", "ffn.3")):
+            out["W:" + k + nm], out["V:" + k + nm + "_b"] = sd[f"{s}.{src}.weight"], sd[f"{s}.{src}.bias"]
+        out[f"V:{k}sd_ln_w"], out[f"V:{k}sd_ln_b"] = sd[s + ".ffn.0.weight"], sd[s + ".ffn.0.bias"]
+        # emb_w was appended in slot order local, global, cross, ffn -- same as STYLE_SLOTS
+        for slot in STYLE_SLOTS:
+            w, b = eph[f"{tag}.{slot}"]
+            eph_w.append(w), eph_b.append(b)
+    out["W:style_eph"], out["V:style_eph_b"] = torch.cat(eph_w, 0), torch.cat(eph_b)
+    out["W:style_emb"], out["V:style_emb_b"] = torch.cat(emb_w, 0), torch.cat(emb_b)
+    return out
+
+
+def _style(out, sd, dst, src):
+    out["V:" + dst + "norm_w"], out["V:" + dst + "norm_b"] = sd[src + ".norm.weight"], sd[src + ".norm.bias"]
+    out["W:" + dst + "out"], out["V:" + dst + "out_b"] = sd[src + ".out_layers.2.weight"], sd[src + ".out_layers.2.bias"]
+
+
+class PackedModel:
+    """Device-resident packed weights + the ctypes ``MdmModel`` that points at them."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: dict, eph, proj, device, with_lo: bool = True,
+                 counters: Dict[str, torch.Tensor] = None):
+        from .ops import PackedWeight  # HIP pack kernel
+
+        self.cfg = dict(cfg)
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise L.MdmError("PackedModel needs a GPU device: the denoising path has no CPU fallback")
+        lay = kernel_layout(sd, cfg, eph, proj)
+        self._keep = []
+        self.W: Dict[str, PackedWeight] = {}
+        self.V: Dict[str, torch.Tensor] = {}
+        with torch.cuda.device(dev):
+            for k, t in lay.items():
+                t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+                if k.startswith("W:"):
+                    self.W[k[2:]] = PackedWeight(t, with_lo=with_lo)
+                else:
+                    self.V[k[2:]] = t
+            D, L_ = cfg["latent_dim"], cfg["num_layers"]
+            self.layers = (L.Layer * (2 * L_))()
+            for li, (pre, tag) in enumerate(layer_tags(L_)):
+                self._fill_layer(self.layers[li], f"L{li}.", pre, counters)
+            m = L.Model()
+            m.D, m.F, m.Dt, m.H = D, cfg["ff_size"], cfg["text_latent_dim"], cfg["num_heads"]
+            m.E, m.L, m.feats, m.num_frames = cfg["moe_num_experts"], L_, cfg["input_feats"], cfg["num_frames"]
+            for n in L._MODEL_PACKED:
+                if n in self.W:
+                    setattr(m, n, self._packed(n))
+            for n in L._MODEL_BIAS:
+                if n in self.V:
+                    setattr(m, n, self.V[n].data_ptr())
+            m.seq_emb = self.V["seq_emb"].data_ptr()
+            m.style_eph, m.style_eph_b = self._packed("style_eph"), self.V["style_eph_b"].data_ptr()
+            m.style_emb, m.style_emb_b = self._packed("style_emb"), self.V["style_emb_b"].data_ptr()
+            m.layers = C.cast(self.layers, C.POINTER(L.Layer))
+            self.model = m
+            torch.cuda.current_stream().synchronize()
+
+    def _packed(self, name: str) -> L.Packed:
+        w = self.W[name]
+        p = L.Packed()
+        p.hi, p.lo, p.ld = w.hi.data_ptr(), (w.lo.data_ptr() if w.lo is not None else 0), w.Kp
+        return p
+
+    def _style(self, st: L.Style, pre: str):
+        st.norm_w, st.norm_b = self.V[pre + "norm_w"].data_ptr(), self.V[pre + "norm_b"].data_ptr()
+        st.out, st.out_b = self._packed(pre + "out"), self.V[pre + "out_b"].data_ptr()
+
+    def _fill_layer(self, l: L.Layer, k: str, sd_prefix: str, counters):
+        V, D = self.V, self.cfg["latent_dim"]
+        l.dual_pre_w, l.dual_pre_b = V[k + "dual_pre_norm_w"].data_ptr(), V[k + "dual_pre_norm_b"].data_ptr()
+        l.dual_post_w, l.dual_post_b = V[k + "dual_post_norm_w"].data_ptr(), V[k + "dual_post_norm_b"].data_ptr()
+        for which, p in (("local", l.local), ("global", l.global_)):
+            q = k + which + "."
+            p.pre_w, p.pre_b = V[q + "pre_norm_w"].data_ptr(), V[q + "pre_norm_b"].data_ptr()
+            p.post_w, p.post_b = V[q + "post_norm_w"].data_ptr(), V[q + "post_norm_b"].data_ptr()
+            p.qkv, p.qkv_b = self._packed(q + "qkv"), V[q + "qkv_b"].data_ptr()
+            p.hn_w, p.hn_b = V[q + "hn_w"].data_ptr(), V[q + "hn_b"].data_ptr()
+            p.feat = self._packed(q + "feat")
+            p.proj0, p.proj0_b = self._packed(q + "proj0"), V[q + "proj0_b"].data_ptr()
+            p.proj3, p.proj3_b = self._packed(q + "proj3"), V[q + "proj3_b"].data_ptr()
+            self._style(p.style, q + "style.")
+        l.skip, l.skip_b = self._packed(k + "skip"), V[k + "skip_b"].data_ptr()
+        l.ca_norm_w, l.ca_norm_b = V[k + "ca_norm_w"].data_ptr(), V[k + "ca_norm_b"].data_ptr()
+        l.ca_tnorm_w, l.ca_tnorm_b = V[k + "ca_tnorm_w"].data_ptr(), V[k + "ca_tnorm_b"].data_ptr()
+        for nm in ("ca_q", "ca_k", "ca_v", "sd_q", "sd_k", "sd_v", "sd_out", "sd_f1", "sd_f2"):
+            setattr(l, nm, self._packed(k + nm))
+            setattr(l, nm + "_b", V[k + nm + "_b"].data_ptr())
+        gvec = torch.empty(D, dtype=torch.float32, device=V[k + "ca_gate"].device)
+        L.check(L.lib().mdm_xattn_gate(C.c_void_p(V[k + "ca_gate"].data_ptr()), C.c_void_p(V[k + "ca_adaptive"].data_ptr()),
+                                       C.c_int32(D), C.c_void_p(gvec.data_ptr()), C.c_void_p(L.stream_ptr())),
+                "mdm_xattn_gate")
+        V[k + "ca_gvec"] = gvec
+        l.ca_gvec = gvec.data_ptr()
+        self._style(l.ca_style, k + "ca_style.")
+        for b in range(2):
+            l.moe_ln_w[b], l.moe_ln_b[b] = V[f"{k}moe_ln_w{b}"].data_ptr(), V[f"{k}moe_ln_b{b}"].data_ptr()
+            l.gate_w[b], l.gate_b[b] = V[f"{k}gate_w{b}"].data_ptr(), V[f"{k}gate_b{b}"].data_ptr()
+            if counters is not None:
+                br = f"{sd_prefix}.ffn.branches.{b}.moe"
+                l.usage[b] = counters[br + ".expert_usage"].data_ptr()
+                l.importance[b] = counters[br + ".expert_importance"].data_ptr()
+        l.w1, l.b1 = self._packed(k + "w1"), V[k + "b1"].data_ptr()
+        l.w2, l.b2 = self._packed(k + "w2"), V[k + "b2"].data_ptr()
+        self._style(l.ffn_style, k + "ffn_style.")
+        l.sd_ln_w, l.sd_ln_b = V[k + "sd_ln_w"].data_ptr(), V[k + "sd_ln_b"].data_ptr()
+
+    def nbytes(self) -> int:
+        n = sum(w.hi.numel() * 2 * (2 if w.lo is not None else 1) for w in self.W.values())
+        return n + sum(v.numel() * 4 for v in self.V.values())

@@ -1,0 +1,323 @@
+"""Drop-in ``MotionTransformer`` whose forward runs on hand-written gfx950 kernels.
+
+Mirrors the reference module's interface (text2motion/models/transformer.py:166-361): same constructor
+keywords, same ``state_dict`` keys/shapes (layout.py), same ``forward(x, timesteps, length, text=None,
+xf_proj=None, xf_out=None)``, ``encode_text``, ``generate_src_mask``, ``num_frames``, MoE counter helpers.
+
+What differs, on purpose:
+  * the reference builds 33 randomly initialised ``nn.Linear`` layers *inside every forward*
+    (stylization.py:22-24, transformer.py:313-315) and draws its Performer feature matrices lazily without saving
+    them (fast_attention.py:33-36).  Here both are explicit state: drawn once (``ephemeral_mode="frozen"``, with
+    the same generators in the same order as the reference's first forward), injectable
+    (``set_ephemerals`` / ``set_projections``) and persistable; ``ephemeral_mode="resample"`` redraws the Linears
+    before every forward exactly like the reference does.
+  * everything that depends only on the text (cross-attention key/value projections and the linear-attention
+    ``softmax(K)^T V`` state) is computed once per distinct ``xf_out`` and cached.
+There is no eager / CPU fallback: without the HIP library or a GPU tensor, forward raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .layout import BUFFER_LEAVES, resolve_dims, state_dict_layout
+from .packing import PackedModel
+from .synth import ephemeral_names, projection_names
+
+
+class _Node(nn.Module):
+    """Anonymous container; only exists so parameter paths spell the reference's state_dict keys."""
+
+
+class MotionTransformer(nn.Module):
+    def __init__(self, input_feats: int, num_frames: int = 60, latent_dim: int = 512, ff_size: int = 1024,
+                 num_layers: int = 4, num_heads: int = 4, dropout: float = 0.1, text_latent_dim: int = 256,
+                 moe_num_experts: int = 4, model_size: str = "small", chunk_size: int = 256, text_encoder=None,
+                 precision: int = 3, ephemeral_mode: str = "frozen", **kwargs):
+        super().__init__()
+        D, F_, Dt = resolve_dims(latent_dim, ff_size, text_latent_dim, model_size)
+        if D % num_heads:
+            raise ValueError("latent_dim must be divisible by num_heads")
+        self.input_feats, self.num_frames = input_feats, num_frames
+        self.latent_dim, self.ff_size, self.text_latent_dim = D, F_, Dt
+        self.num_layers, self.num_heads, self.dropout = num_layers, num_heads, dropout
+        self.moe_num_experts, self.chunk_size = moe_num_experts, chunk_size
+        self.time_embed_dim = 4 * D
+        self.precision = precision
+        if ephemeral_mode not in ("frozen", "resample"):
+            raise ValueError("ephemeral_mode must be 'frozen' or 'resample'")
+        self.ephemeral_mode = ephemeral_mode
+        self._layout = state_dict_layout(input_feats, num_frames, latent_dim, ff_size, num_layers, num_heads,
+                                         text_latent_dim, moe_num_experts, model_size)
+        for key, shape in self._layout:
+            node = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            if parts[-1] in BUFFER_LEAVES:
+                node.register_buffer(parts[-1], torch.zeros(shape))
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape)))
+        self.text_encoder_fn = text_encoder  # callable(text, device) -> (xf_proj (B,Dt), xf_out (B,N,Dt))
+        self._eph: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None
+        self._proj: Optional[Dict[str, torch.Tensor]] = None
+        self._packed: Optional[PackedModel] = None
+        self._text_cache = None
+        self._ws: Optional[torch.Tensor] = None
+        self._uncond: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self.reset_parameters()
+        self.register_load_state_dict_post_hook(lambda mod, _: mod.invalidate())
+
+    # ------------------------------------------------------------------------------------------------
+    # parameters / captured randomness
+    # ------------------------------------------------------------------------------------------------
+    def kernel_cfg(self) -> dict:
+        return dict(latent_dim=self.latent_dim, ff_size=self.ff_size, text_latent_dim=self.text_latent_dim,
+                    num_heads=self.num_heads, num_layers=self.num_layers, moe_num_experts=self.moe_num_experts,
+                    input_feats=self.input_feats, num_frames=self.num_frames)
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        """Same distributions as the reference constructors: nn.Linear/Conv defaults, LayerNorm (1,0), randn
+        sequence embedding, xavier_normal(gain=0.1) on every >=2-D Performer parameter (fast_attention.py:132-135),
+        zeros for the MoE gates, cross-attn gates, StylizationBlock out layers and the output head
+        (switch_moe.py:28-29, fast_attention.py:240,267, stylization.py:17, transformer.py:257)."""
+        lay = dict(self._layout)
+        for key, p in self.state_dict(keep_vars=True).items():
+            leaf = key.rsplit(".", 1)[-1]
+            performer = ".local_attn." in key or ".global_attn." in key
+            if leaf in BUFFER_LEAVES:
+                p.zero_()
+            elif key == "sequence_embedding":
+                p.normal_()
+            elif leaf in ("gate", "adaptive_gate") or ".moe.gate." in key or key.startswith("out."):
+                p.zero_()
+            elif ".out_layers.2." in key and not performer:
+                p.zero_()
+            elif p.dim() == 1:
+                wshape = lay.get(key[:-len(leaf)] + "weight")
+                if leaf == "weight":
+                    p.fill_(1.0)  # LayerNorm gain
+                elif wshape is not None and len(wshape) == 1:
+                    p.zero_()  # LayerNorm bias
+                else:  # Linear / Conv bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                    fan_in = wshape[1] * (wshape[2] if len(wshape) == 3 else 1)
+                    p.uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+            elif performer:
+                nn.init.xavier_normal_(p, gain=0.1)
+            else:  # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                fan_in = p.shape[1] * (p.shape[2] if p.dim() == 3 else 1)
+                p.uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+        self.invalidate()
+
+    def invalidate(self):
+        """Forget packed weights / caches (call after mutating parameters in place)."""
+        self._packed = None
+        self._text_cache = None
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.invalidate()
+        return r
+
+    @property
+    def device(self) -> torch.device:
+        return self.sequence_embedding.device
+
+    def set_ephemerals(self, items):
+        """items: ordered iterable of (name, weight, bias) or {name: (weight, bias)} for synth.ephemeral_names()."""
+        d = {n: (w, b) for n, w, b in items} if not isinstance(items, dict) else dict(items)
+        need = ephemeral_names(self.num_layers, self.text_latent_dim != self.latent_dim)
+        missing = [n for n in need if n not in d]
+        if missing:
+            raise ValueError(f"missing ephemeral projections: {missing[:3]}...")
+        self._eph = {n: d[n] for n in need}
+        self.invalidate()
+
+    def set_projections(self, items):
+        d = dict(items)
+        need = projection_names(self.num_layers)
+        dh = self.latent_dim // self.num_heads
+        for n in need:
+            if tuple(d[n].shape) != (dh, min(dh, 256)):
+                raise ValueError(f"projection {n} must be ({dh},{min(dh, 256)})")
+        self._proj = {n: d[n] for n in need}
+        self.invalidate()
+
+    def captured_state(self) -> dict:
+        """The random state the reference never saves; store it next to a checkpoint to reproduce samples."""
+        return {"ephemerals": self._eph, "projections": self._proj}
+
+    @torch.no_grad()
+    def draw_ephemerals(self):
+        """Draw the per-forward Linears the way the reference does: nn.Linear(...) constructed on the CPU,
+        consuming the CPU default generator, in call order (stylization.py:23, transformer.py:314)."""
+        eph = {}
+        for n in ephemeral_names(self.num_layers, self.text_latent_dim != self.latent_dim):
+            lin = nn.Linear(self.text_latent_dim, self.latent_dim) if n == "text_proj" else \
+                nn.Linear(self.latent_dim, self.time_embed_dim)
+            eph[n] = (lin.weight.detach().clone(), lin.bias.detach().clone())
+        self._eph = eph
+        self.invalidate()
+
+    @torch.no_grad()
+    def draw_projections(self):
+        """fast_attention.py:19-27: QR of randn(dh, 256) drawn on the module's device, column-normalised, * dh^-1/4."""
+        dh = self.latent_dim // self.num_heads
+        proj = {}
+        for n in projection_names(self.num_layers):
+            g = torch.randn(dh, 256, device=self.device)
+            q, _ = torch.linalg.qr(g, mode="reduced")
+            proj[n] = torch.nn.functional.normalize(q, dim=0) * (dh ** -0.25)
+        self._proj = proj
+        self.invalidate()
+
+    # ------------------------------------------------------------------------------------------------
+    # reference helper API
+    # ------------------------------------------------------------------------------------------------
+    def moe_buffers(self) -> Dict[str, torch.Tensor]:
+        return {k: v for k, v in self.named_buffers() if k.rsplit(".", 1)[-1] in BUFFER_LEAVES}
+
+    def reset_all_moe_counters(self, model=None):
+        for b in (model or self).moe_buffers().values():
+            b.zero_()
+
+    def get_moe_loss(self, model=None):
+        """Sum over MoE layers of E * sum(importance_frac * usage_frac) (switch_moe.py:113-145); counters only,
+        i.e. the value the reference computes, without a graph (training is out of scope)."""
+        m = model or self
+        bufs = m.moe_buffers()
+        total = torch.zeros((), device=self.device)
+        for k, usage in bufs.items():
+            if not k.endswith("expert_usage"):
+                continue
+            imp = bufs[k.replace("expert_usage", "expert_importance")]
+            u = usage / usage.sum().clamp_min(1e-8)
+            i = imp / imp.sum().clamp_min(1e-8)
+            total = total + usage.numel() * (u * i).sum()
+        return total
+
+    def get_total_moe_loss(self, model=None, moe_coef=0.01):
+        return moe_coef * self.get_moe_loss(model)
+
+    def encode_text(self, text: List[str], device):
+        if self.text_encoder_fn is None:
+            raise L.MdmError(
+                "no text encoder attached: the reference's DeBERTa-v3-large weights are a network fetch "
+                "(text_encoder.py:9-11) and are out of scope here; pass text_encoder=callable(text, device) -> "
+                "(xf_proj, xf_out), or call forward with xf_proj/xf_out")
+        return self.text_encoder_fn(text, device)
+
+    def set_uncond_embedding(self, xf_proj: torch.Tensor, xf_out: torch.Tensor):
+        """Cached embedding of the empty caption used by classifier-free guidance (one row, broadcast over B)."""
+        self._uncond = (xf_proj, xf_out)
+
+    def uncond_embedding(self, B: int, device):
+        if self._uncond is None:
+            xp, xo = self.encode_text([""], device)
+            self._uncond = (xp[:1].contiguous(), xo[:1].contiguous())
+        xp, xo = self._uncond
+        return xp.to(device).expand(B, -1).contiguous(), xo.to(device).expand(B, -1, -1).contiguous()
+
+    def generate_src_mask(self, T: int, length: torch.Tensor) -> torch.Tensor:
+        return (torch.arange(T, device=length.device)[None, :] < length[:, None]).to(torch.float32)
+
+    # ------------------------------------------------------------------------------------------------
+    # HIP path
+    # ------------------------------------------------------------------------------------------------
+    def pack(self) -> PackedModel:
+        if self.device.type != "cuda":
+            raise L.MdmError("MotionTransformer runs on hand-written HIP kernels only: move it to a GPU "
+                             "(no CPU/eager fallback exists)")
+        if self._eph is None:
+            self.draw_ephemerals()
+        if self._proj is None:
+            self.draw_projections()
+        if self._packed is None:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._packed = PackedModel(sd, self.kernel_cfg(), self._eph, self._proj, self.device,
+                                       with_lo=True, counters=self.moe_buffers())
+            self._text_cache = None
+        return self._packed
+
+    def _workspace(self, B: int, T: int, N: int) -> torch.Tensor:
+        pm = self.pack()
+        need = L.lib().mdm_workspace_bytes(C.byref(pm.model), C.c_int32(B), C.c_int32(T), C.c_int32(N))
+        if need < 0:
+            raise L.MdmError("unsupported model shape for the HIP path")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def prepare_text(self, xf_out: torch.Tensor):
+        """Build (or fetch) the text-side cache for this xf_out [B,N,Dt]."""
+        pm = self.pack()
+        xf_out = xf_out.detach().to(torch.float32).contiguous()
+        B, N, Dt = xf_out.shape
+        if Dt != self.text_latent_dim:
+            raise ValueError(f"xf_out last dim {Dt} != text_latent_dim {self.text_latent_dim}")
+        key = (xf_out.data_ptr(), xf_out._version, B, N, self.precision)
+        if self._text_cache is not None and self._text_cache["key"] == key:
+            return self._text_cache
+        D, H, L2 = self.latent_dim, self.num_heads, 2 * self.num_layers
+        dh = D // H
+        dev = self.device
+        at = torch.empty((L2, B, H, dh, dh), dtype=torch.float32, device=dev)
+        sk = torch.empty((L2, B, N, D), dtype=torch.float32, device=dev)
+        sv = torch.empty((L2, B, N, D), dtype=torch.float32, device=dev)
+        tc = L.TextCache()
+        tc.lin_at, tc.sd_k, tc.sd_v, tc.B, tc.N = at.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, N
+        ws = self._workspace(B, 2, N)
+        L.check(L.lib().mdm_text_cache_build(C.byref(pm.model), C.c_void_p(xf_out.data_ptr()), C.byref(tc),
+                                             C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
+                                             C.c_void_p(L.stream_ptr())), "mdm_text_cache_build")
+        self._text_cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out), "B": B, "N": N}
+        return self._text_cache
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, timesteps: torch.Tensor, length: torch.Tensor,
+                text: Optional[List[str]] = None, xf_proj=None, xf_out=None, *, forced_routing=None,
+                trace: bool = False, out: Optional[torch.Tensor] = None):
+        if not x.is_cuda:
+            raise L.MdmError("MotionTransformer.forward needs GPU tensors: the denoiser runs on HIP kernels only")
+        B, T, Fe = x.shape
+        if Fe != self.input_feats:
+            raise ValueError(f"expected {self.input_feats} features, got {Fe}")
+        if T % 2:
+            raise ValueError("T must be even: the reference's 2-scale U-shape cannot add skip and upsampled "
+                             "tensors of different lengths (transformer.py:223-224,353)")
+        if T > self.num_frames:
+            raise ValueError(f"T={T} exceeds num_frames={self.num_frames}")
+        if xf_proj is None or xf_out is None:
+            xf_proj, xf_out = self.encode_text(text, x.device)
+        if self.ephemeral_mode == "resample":
+            self.draw_ephemerals()
+        pm = self.pack()
+        tcache = self.prepare_text(xf_out)
+        if tcache["B"] != B:
+            raise ValueError("xf_out batch does not match x")
+        dev = x.device
+        x = x.detach().to(torch.float32).contiguous()
+        ts = timesteps.detach().to(device=dev, dtype=torch.int64).contiguous()
+        ln = length.detach().to(device=dev, dtype=torch.int32).contiguous()
+        xp = xf_proj.detach().to(device=dev, dtype=torch.float32).contiguous()
+        ws = self._workspace(B, T, tcache["N"])
+        if out is None:
+            out = torch.empty((B, T, Fe), dtype=torch.float32, device=dev)
+        fr = forced_routing.to(device=dev, dtype=torch.int32).contiguous() if forced_routing is not None else None
+        tr = torch.zeros((2 * self.num_layers, 4, B * T, self.latent_dim), dtype=torch.float32, device=dev) if trace else None
+        L.check(L.lib().mdm_denoiser_forward(
+            C.byref(pm.model), C.byref(tcache["tc"]), C.c_void_p(x.data_ptr()), C.c_void_p(ts.data_ptr()),
+            C.c_void_p(ln.data_ptr()), C.c_void_p(xp.data_ptr()), C.c_int32(B), C.c_int32(T), C.c_void_p(out.data_ptr()),
+            C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(L.ptr(fr)), C.c_void_p(L.ptr(tr)),
+            C.c_int32(self.precision), C.c_void_p(L.stream_ptr())), "mdm_denoiser_forward")
+        if trace:
+            return out, tr
+        return out

@@ -58,3 +58,18 @@ def golden_state(meta):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def build_module(meta, device="cuda", precision=3):
+    """Our MotionTransformer for a golden case: synthetic weights + injected captured randomness."""
+    T = pkg("transformer")
+    cfg = meta["cfg"]
+    sd, eph, proj, mcfg = golden_state(meta)
+    m = T.MotionTransformer(cfg["input_feats"], num_frames=cfg["num_frames"], latent_dim=cfg["latent_dim_arg"],
+                            ff_size=cfg["ff_size_arg"], num_layers=cfg["num_layers"], num_heads=cfg["num_heads"],
+                            text_latent_dim=cfg["text_latent_dim_arg"], moe_num_experts=cfg["moe_num_experts"],
+                            model_size=cfg["model_size"], precision=precision)
+    m.load_state_dict(sd, strict=True)
+    m.set_ephemerals(eph)
+    m.set_projections(proj)
+    return m.to(device).eval(), (sd, eph, proj, mcfg)
