@@ -175,10 +175,11 @@ int mdm_stem_embeddings(const MdmModel* m, const int64_t* timesteps, const float
 /* Sampler updates on n = B*T*feats elements.  tab = fp32 schedule table [7][steps] with rows
  * sqrt_recip_acp, sqrt_recipm1_acp, coef1, coef2, post_logvar_clipped, acp, acp_prev
  * (gaussian_diffusion.py:405-431); t from *t_dev when non-NULL else t_imm.
- * CFG DDPM step (gaussian_diffusion.py:1042-1098; eps_u NULL = unguided p_sample :582-614; noise NULL = no noise). */
+ * CFG DDPM step (gaussian_diffusion.py:1042-1098; eps_u NULL = unguided p_sample :582-614; noise NULL = no noise;
+ * clip_denoised clamps each pred_xstart to [-1,1] before guidance, :523-528). */
 int mdm_cfg_posterior_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n,
                            const float* tab, int32_t steps, const int32_t* t_dev, int32_t t_imm, float cfg_scale,
-                           float* x_out, float* x0_out, void* stream);
+                           int32_t clip_denoised, float* x_out, float* x0_out, void* stream);
 /* DDIM step (gaussian_diffusion.py:699-742). */
 int mdm_ddim_step(const float* x, const float* eps, const float* noise, int64_t n, const float* tab, int32_t steps,
                   const int32_t* t_dev, int32_t t_imm, float eta, int32_t clip_denoised, float* x_out, float* x0_out,

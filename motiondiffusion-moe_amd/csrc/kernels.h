@@ -41,7 +41,7 @@ int halve_lengths(const int* len, int B, int* out, hipStream_t s);
 int fill_i64(int64_t* dst, int64_t n, const int* src, hipStream_t s);
 int add_i32(int* dst, int delta, hipStream_t s);
 int cfg_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n, const float* tab,
-             int ts, const int* t_ptr, int t_imm, float cfg_scale, float* x_out, float* x0_out, hipStream_t s);
+             int ts, const int* t_ptr, int t_imm, float cfg_scale, int clip, float* x_out, float* x0_out, hipStream_t s);
 int ddim_step(const float* x, const float* eps, const float* noise, int64_t n, const float* tab, int ts,
               const int* t_ptr, int t_imm, float eta, int clip, float* x_out, float* x0_out, hipStream_t s);
 

@@ -492,9 +492,10 @@ int mdm_stylization_forward(const MdmStyle* st, const float* h, const float* sc,
 
 int mdm_cfg_posterior_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n,
                            const float* tab, int32_t steps, const int32_t* t_dev, int32_t t_imm, float cfg_scale,
-                           float* x_out, float* x0_out, void* stream) {
+                           int32_t clip_denoised, float* x_out, float* x0_out, void* stream) {
   if (steps <= 0 || (!t_dev && (t_imm < 0 || t_imm >= steps))) return MDM_ERR_ARG;
-  return cfg_step(x, eps_c, eps_u, noise, n, tab, steps, t_dev, t_imm, cfg_scale, x_out, x0_out, (hipStream_t)stream);
+  return cfg_step(x, eps_c, eps_u, noise, n, tab, steps, t_dev, t_imm, cfg_scale, clip_denoised, x_out, x0_out,
+                  (hipStream_t)stream);
 }
 
 int mdm_ddim_step(const float* x, const float* eps, const float* noise, int64_t n, const float* tab, int32_t steps,

@@ -419,7 +419,7 @@ __global__ void halve_lengths_kernel(const int* __restrict__ len, int B, int* __
 // ---- sampler updates (gaussian_diffusion.py:554-558, 462-475, 1075-1096, 725-742) ---------------
 __global__ void cfg_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
                                 const float* __restrict__ eps_u, const float* __restrict__ noise, int64_t n,
-                                const float* __restrict__ tab, int ts, const int* __restrict__ t_ptr, int t_imm, float cfg_scale,
+                                const float* __restrict__ tab, int ts, const int* __restrict__ t_ptr, int t_imm, float cfg_scale, int clip,
                                 float* __restrict__ x_out, float* __restrict__ x0_out) {
   const int t = t_ptr ? *t_ptr : t_imm;
   const float a = tab[TAB_SQRT_RECIP * ts + t], b = tab[TAB_SQRT_RECIPM1 * ts + t];
@@ -427,10 +427,12 @@ __global__ void cfg_step_kernel(const float* __restrict__ x, const float* __rest
   const float sd = t == 0 ? 0.f : expf(0.5f * tab[TAB_LOGVAR * ts + t]);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float xv = x[i];
-    const float x0c = a * xv - b * eps_c[i];
+    float x0c = a * xv - b * eps_c[i];
+    if (clip) x0c = fminf(fmaxf(x0c, -1.f), 1.f);
     float x0 = x0c;
     if (eps_u) {
-      const float x0u = a * xv - b * eps_u[i];
+      float x0u = a * xv - b * eps_u[i];
+      if (clip) x0u = fminf(fmaxf(x0u, -1.f), 1.f);
       x0 = x0u + cfg_scale * (x0c - x0u);
     }
     const float mean = c1 * x0 + c2 * xv;
@@ -604,12 +606,12 @@ int add_i32(int* dst, int delta, hipStream_t s) {
 }
 
 int cfg_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n, const float* tab,
-             int ts, const int* t_ptr, int t_imm, float cfg_scale, float* x_out, float* x0_out, hipStream_t s) {
+             int ts, const int* t_ptr, int t_imm, float cfg_scale, int clip, float* x_out, float* x0_out, hipStream_t s) {
   if (n <= 0) return MDM_OK;
   if (!x || !eps_c || !tab || !x_out) return MDM_ERR_ARG;
   int blocks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(cfg_step_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, s, x, eps_c, eps_u, noise, n,
-                     tab, ts, t_ptr, t_imm, cfg_scale, x_out, x0_out);
+                     tab, ts, t_ptr, t_imm, cfg_scale, clip, x_out, x0_out);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

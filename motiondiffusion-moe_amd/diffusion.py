@@ -1,0 +1,313 @@
+"""``GaussianDiffusion`` sampling API of the reference (text2motion/models/gaussian_diffusion.py) on HIP.
+
+Kept: constructor keywords, the f64 numpy schedule attributes, ``p_sample_loop_with_cfg`` (:1100-1141, the loop the
+trainer uses), ``ddim_sample_loop`` (:744-774), ``p_sample_loop`` (:616-646, with the evidently intended noise draw:
+the reference calls ``randn_like`` with a shape and raises TypeError at :606), and the single-step methods.
+Only the configuration the trainer builds is implemented on the device -- EPSILON mean, FIXED_SMALL / FIXED_LARGE
+variance (ddpm_trainer.py:45-50); learned-variance / x0-prediction variants and the training losses are out of
+scope and raise NotImplementedError.
+
+One denoising step = one C call chain captured into a hipGraph:
+   [cond | uncond] rows batched as 2B through mdm_denoiser_forward  ->  mdm_cfg_posterior_step (guidance on
+   pred_xstart, posterior mean, noise)  ->  t -= 1 on the device.
+The unconditional text embedding is encoded once and cached instead of re-running the text encoder on [""]*B every
+step (gaussian_diffusion.py:1059-1062); in eval mode that is bit-identical.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import math
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class LossType(enum.Enum):
+    MSE = enum.auto()
+    RESCALED_MSE = enum.auto()
+    KL = enum.auto()
+    RESCALED_KL = enum.auto()
+
+    def is_vb(self):
+        return self in (LossType.KL, LossType.RESCALED_KL)
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    return np.array([min(1 - alpha_bar((i + 1) / num_diffusion_timesteps) / alpha_bar(i / num_diffusion_timesteps), max_beta)
+                     for i in range(num_diffusion_timesteps)])
+
+
+def get_named_beta_schedule(schedule_name: str, num_diffusion_timesteps: int) -> np.ndarray:
+    """gaussian_diffusion.py:19-55 ('linear' is what the trainer uses; scaled by 1000/steps)."""
+    n = num_diffusion_timesteps
+    if schedule_name == "linear":
+        scale = 1000 / n
+        return np.linspace(scale * 0.0001, scale * 0.02, n, dtype=np.float64)
+    if schedule_name == "cosine":
+        return betas_for_alpha_bar(n, lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2)
+    if schedule_name == "sqrt":
+        alphas = np.linspace(1.0, 0.0, n, dtype=np.float64)
+        betas = 1 - alphas ** 2
+        betas = (betas - betas.min()) / (betas.max() - betas.min())
+        return betas * (0.02 - 0.0001) + 0.0001
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+class GaussianDiffusion:
+    def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False, cfg_scale=7.5):
+        self.model_mean_type, self.model_var_type, self.loss_type = model_mean_type, model_var_type, loss_type
+        self.rescale_timesteps, self.cfg_scale = rescale_timesteps, cfg_scale
+        betas = np.array(betas, dtype=np.float64)
+        self.betas = betas
+        assert betas.ndim == 1, "betas must be 1-D"
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self._tab_cache = {}
+
+    # ---- host logic ---------------------------------------------------------------------------------
+    def schedule_table(self) -> np.ndarray:
+        """fp32 [7, steps] table handed to the step kernels: each f64 entry rounded to f32 exactly as
+        _extract_into_tensor does (gaussian_diffusion.py:329-341)."""
+        if self.model_var_type == ModelVarType.FIXED_SMALL:
+            logvar = self.posterior_log_variance_clipped
+        elif self.model_var_type == ModelVarType.FIXED_LARGE:
+            logvar = np.log(np.append(self.posterior_variance[1], self.betas[1:]))
+        else:
+            raise NotImplementedError("learned-variance models are out of scope of the HIP sampler")
+        rows = [self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
+                self.posterior_mean_coef2, logvar, self.alphas_cumprod, self.alphas_cumprod_prev]
+        return np.stack(rows).astype(np.float32)
+
+    def _device_table(self, device) -> torch.Tensor:
+        key = str(device)
+        if key not in self._tab_cache:
+            self._tab_cache[key] = torch.from_numpy(self.schedule_table()).to(device).contiguous()
+        return self._tab_cache[key]
+
+    def _check_supported(self, denoised_fn=None, cond_fn=None):
+        if self.model_mean_type != ModelMeanType.EPSILON:
+            raise NotImplementedError("only epsilon-prediction models are implemented (ddpm_trainer.py:47)")
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn hooks are not supported by the fused HIP step")
+        if self.rescale_timesteps:
+            raise NotImplementedError("rescale_timesteps would feed float timesteps; the denoiser takes int64 steps")
+
+    def _scale_timesteps(self, t):
+        return t
+
+    # ---- fused step drivers ----------------------------------------------------------------------------
+    def _runner(self, model, shape, model_kwargs, device, mode: str, cfg_scale: float, eta: float, clip: bool,
+                use_graph: bool):
+        return _StepRunner(self, model, tuple(shape), model_kwargs or {}, device, mode, cfg_scale, eta, clip, use_graph)
+
+    @torch.no_grad()
+    def p_sample_loop_with_cfg(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
+                               device=None, progress=False, cfg_scale=7.5, *, step_noise=None, use_graph=True,
+                               callback: Optional[Callable] = None):
+        """Classifier-free-guided ancestral sampling.  ``step_noise``: optional list/tensor of per-step noise (the
+        reference draws ``randn_like`` each step, :1094); ``callback(i, t, x)`` is called after every step."""
+        self._check_supported(denoised_fn)
+        r = self._runner(model, shape, model_kwargs, device, "cfg", cfg_scale, 0.0, clip_denoised, use_graph)
+        return r.run(noise, step_noise, progress, callback)
+
+    @torch.no_grad()
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False, before_step_fn=None, *, step_noise=None,
+                      use_graph=True):
+        """Unguided ancestral sampling with the intended noise draw (the reference's version raises at :606)."""
+        self._check_supported(denoised_fn, cond_fn)
+        r = self._runner(model, shape, model_kwargs, device, "ddpm", 0.0, 0.0, clip_denoised, use_graph)
+        cb = (lambda i, t, x: before_step_fn(t, x)) if before_step_fn is not None else None
+        return r.run(noise, step_noise, progress, cb)
+
+    @torch.no_grad()
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, *, step_noise=None, use_graph=True):
+        self._check_supported(denoised_fn, cond_fn)
+        r = self._runner(model, shape, model_kwargs, device, "ddim", 0.0, eta, clip_denoised, use_graph)
+        return r.run(noise, step_noise, progress, None)
+
+    # single steps (eager): same arithmetic, returns {"sample", "pred_xstart"}
+    @torch.no_grad()
+    def p_sample_with_cfg(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, cfg_scale=7.5,
+                          noise=None):
+        self._check_supported(denoised_fn)
+        r = self._runner(model, x.shape, model_kwargs, x.device, "cfg", cfg_scale, 0.0, clip_denoised, False)
+        return r.single(x, t, noise)
+
+    @torch.no_grad()
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0,
+                    noise=None):
+        self._check_supported(denoised_fn, cond_fn)
+        r = self._runner(model, x.shape, model_kwargs, x.device, "ddim", 0.0, eta, clip_denoised, False)
+        return r.single(x, t, noise)
+
+    @torch.no_grad()
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, noise=None):
+        self._check_supported(denoised_fn, cond_fn)
+        r = self._runner(model, x.shape, model_kwargs, x.device, "ddpm", 0.0, 0.0, clip_denoised, False)
+        return r.single(x, t, noise)
+
+
+class _StepRunner:
+    """Static buffers + (optionally) one captured hipGraph for a whole denoising step."""
+
+    def __init__(self, diff: GaussianDiffusion, model, shape, kw, device, mode, cfg_scale, eta, clip, use_graph):
+        self.d, self.model, self.mode = diff, model, mode
+        self.cfg_scale, self.eta, self.clip, self.use_graph = float(cfg_scale), float(eta), bool(clip), use_graph
+        if device is None:
+            device = next(model.parameters()).device
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise L.MdmError("the sampler runs on HIP kernels only: model and tensors must live on a GPU")
+        B, T, Fe = shape
+        self.B, self.T, self.Fe = B, T, Fe
+        self.n = B * T * Fe
+        length = kw.get("length")
+        if length is None:
+            raise ValueError("model_kwargs['length'] is required (ddpm_trainer.py:166-171)")
+        length = torch.as_tensor(length).to(self.dev, torch.int32)
+        if getattr(model, "ephemeral_mode", "frozen") == "resample":
+            self.use_graph = False  # fresh random projections are drawn on the host before every forward
+        xp, xo = kw.get("xf_proj"), kw.get("xf_out")
+        if xp is None or xo is None:
+            xp, xo = model.encode_text(kw["text"], self.dev)
+        xp, xo = xp.to(self.dev, torch.float32), xo.to(self.dev, torch.float32)
+        if mode == "cfg":  # cond rows then uncond rows of the same samples, one forward of 2B rows
+            up, uo = kw.get("xf_proj_uncond"), kw.get("xf_out_uncond")
+            if up is None or uo is None:
+                up, uo = model.uncond_embedding(B, self.dev)
+            if uo.shape[1] != xo.shape[1]:
+                raise ValueError("cond and uncond text embeddings must have the same token count to be batched "
+                                 f"({xo.shape[1]} vs {uo.shape[1]}): pad the shorter one the way the tokenizer pads")
+            self.xp = torch.cat([xp, up.to(self.dev, torch.float32)], 0).contiguous()
+            self.xo = torch.cat([xo, uo.to(self.dev, torch.float32)], 0).contiguous()
+            self.len2 = torch.cat([length, length], 0)
+            self.R = 2 * B
+        else:
+            self.xp, self.xo, self.len2, self.R = xp.contiguous(), xo.contiguous(), length, B
+        self.xx = torch.empty((self.R, T, Fe), dtype=torch.float32, device=self.dev)  # model input rows
+        self.eps = torch.empty_like(self.xx)
+        self.noise = torch.empty((B, T, Fe), dtype=torch.float32, device=self.dev)
+        self.x0 = torch.empty_like(self.noise)
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.ts = torch.zeros(self.R, dtype=torch.int64, device=self.dev)
+        self.tab = diff._device_table(self.dev)
+        self.graph = None
+
+    # one step on the current stream: reads self.xx[:B] (x_t), writes x_{t-1} back into it
+    def _step(self, use_noise: bool):
+        lib, s = L.lib(), C.c_void_p(L.stream_ptr())
+        B, n = self.B, self.n
+        x = self.xx[:B]
+        if self.R == 2 * B:
+            self.xx[B:].copy_(x)
+        L.check(lib.mdm_fill_i64(C.c_void_p(self.ts.data_ptr()), C.c_int64(self.R), C.c_void_p(self.t_dev.data_ptr()), s))
+        self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps)
+        noise = C.c_void_p(self.noise.data_ptr() if use_noise else 0)
+        steps = C.c_int32(self.d.num_timesteps)
+        if self.mode == "ddim":
+            L.check(lib.mdm_ddim_step(C.c_void_p(x.data_ptr()), C.c_void_p(self.eps.data_ptr()), noise, C.c_int64(n),
+                                      C.c_void_p(self.tab.data_ptr()), steps, C.c_void_p(self.t_dev.data_ptr()), C.c_int32(0),
+                                      C.c_float(self.eta), C.c_int32(int(self.clip)), C.c_void_p(x.data_ptr()),
+                                      C.c_void_p(self.x0.data_ptr()), s), "mdm_ddim_step")
+        else:
+            eps_u = self.eps[B:].data_ptr() if self.mode == "cfg" else 0
+            L.check(lib.mdm_cfg_posterior_step(C.c_void_p(x.data_ptr()), C.c_void_p(self.eps.data_ptr()), C.c_void_p(eps_u),
+                                               noise, C.c_int64(n), C.c_void_p(self.tab.data_ptr()), steps,
+                                               C.c_void_p(self.t_dev.data_ptr()), C.c_int32(0), C.c_float(self.cfg_scale),
+                                               C.c_int32(int(self.clip)), C.c_void_p(x.data_ptr()),
+                                               C.c_void_p(self.x0.data_ptr()), s), "mdm_cfg_posterior_step")
+        L.check(lib.mdm_add_i32(C.c_void_p(self.t_dev.data_ptr()), C.c_int32(-1), s))
+
+    def _needs_noise(self) -> bool:
+        return not (self.mode == "ddim" and self.eta == 0.0)
+
+    def _prepare(self):
+        """Pack weights, build the text cache, size the workspace -- everything that allocates -- before capture.
+        The warm-up forward must not disturb the MoE counters the reference would show (switch_moe.py:71-92)."""
+        saved = {k: v.clone() for k, v in self.model.moe_buffers().items()} if hasattr(self.model, "moe_buffers") else {}
+        self.xx.zero_()
+        self.t_dev.fill_(self.d.num_timesteps - 1)
+        self.noise.zero_()
+        self._step(self._needs_noise())
+        for k, v in saved.items():
+            self.model.moe_buffers()[k].copy_(v)
+        torch.cuda.current_stream().synchronize()
+
+    def run(self, noise, step_noise, progress, callback):
+        d, B = self.d, self.B
+        self._prepare()
+        if self.use_graph:
+            g = torch.cuda.CUDAGraph()
+            saved = {k: v.clone() for k, v in self.model.moe_buffers().items()}
+            with torch.cuda.graph(g):
+                self._step(self._needs_noise())
+            for k, v in saved.items():  # capture does not execute, but keep the invariant explicit
+                self.model.moe_buffers()[k].copy_(v)
+            self.graph = g
+        if noise is None:
+            noise = torch.randn((B, self.T, self.Fe), device=self.dev)
+        self.xx[:B].copy_(noise.to(self.dev, torch.float32))
+        self.t_dev.fill_(d.num_timesteps - 1)
+        it = range(d.num_timesteps)
+        if progress:
+            from tqdm.auto import tqdm
+            it = tqdm(it, desc="Sampling")
+        for i in it:
+            if self._needs_noise():
+                if step_noise is not None:
+                    self.noise.copy_(step_noise[i].to(self.dev, torch.float32))
+                else:
+                    self.noise.normal_()
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._step(self._needs_noise())
+            if callback is not None:
+                callback(i, d.num_timesteps - 1 - i, self.xx[:B])
+        return self.xx[:B].clone()
+
+    def single(self, x, t, noise):
+        t = torch.as_tensor(t)
+        t0 = int(t.flatten()[0])
+        if t.numel() > 1 and not bool((t == t0).all()):
+            raise NotImplementedError("per-sample timesteps within one sampler step are not supported; "
+                                      "call the model directly for that")
+        self.xx[:self.B].copy_(x.to(self.dev, torch.float32))
+        self.t_dev.fill_(t0)
+        use_noise = self._needs_noise()
+        if use_noise:
+            self.noise.copy_(noise.to(self.dev, torch.float32)) if noise is not None else self.noise.normal_()
+        self._step(use_noise)
+        return {"sample": self.xx[:self.B].clone(), "pred_xstart": self.x0.clone()}

@@ -1,0 +1,70 @@
+"""Batch-parallel sampling over the GPUs of one node.
+
+Samples never interact inside the denoiser or the sampler, so the global batch is cut into contiguous per-rank
+shards (each sample's cond+uncond pair stays on its rank), weights are replicated, there is no per-step
+collective, and the only exchange is ONE all_gather of the final (B/world, T, feats) motion tensor
+(RCCL over xGMI on GPUs; gloo in the CPU tests).  The global x_T and per-step noise are drawn for the
+*global* batch from one seeded generator and sliced, so results do not depend on the world size.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(B: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split: the first B % world ranks get one extra sample."""
+    q, r = divmod(B, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_kwargs(kw: Dict, lo: int, hi: int) -> Dict:
+    out = {}
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor) and v.dim() >= 1:
+            out[k] = v[lo:hi]
+        elif isinstance(v, (list, tuple)):
+            out[k] = v[lo:hi]
+        else:
+            out[k] = v
+    return out
+
+
+def global_noise(shape, seed: int, steps: int = 0):
+    """x_T (and optionally per-step noise) for the GLOBAL batch, from a CPU generator (world-size invariant)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x_T = torch.randn(shape, generator=g)
+    step = [torch.randn(shape, generator=g) for _ in range(steps)]
+    return x_T, step
+
+
+def all_gather_ragged(local: torch.Tensor, B: int, group=None) -> torch.Tensor:
+    """all_gather of shards whose first dim may differ by one: pad to the max shard, gather once, trim."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    rank = dist.get_rank(group)
+    sizes = [shard_range(B, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    parts = [out[r * mx:r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
+    return torch.cat(parts, 0)
+
+
+def sample_sharded(sample_fn, shape, model_kwargs: Dict, seed: int, steps_with_noise: int = 0, group=None):
+    """Run ``sample_fn(local_shape, local_kwargs, x_T_local, step_noise_local) -> (b, T, F)`` on this rank's shard
+    of the global batch and all_gather the result.  Works with any backend (nccl == RCCL on ROCm, gloo on CPU)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = shape[0]
+    lo, hi = shard_range(B, rank, world)
+    x_T, step = global_noise(tuple(shape), seed, steps_with_noise)
+    local_kw = shard_kwargs(model_kwargs, lo, hi)
+    local = sample_fn((hi - lo,) + tuple(shape[1:]), local_kw, x_T[lo:hi], [s[lo:hi] for s in step] if step else None)
+    return all_gather_ragged(local, B, group)

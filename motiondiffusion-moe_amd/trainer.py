@@ -1,0 +1,79 @@
+"""Sampling half of the reference's ``DDPMTrainer`` (text2motion/trainers/ddpm_trainer.py:28-71,145-199,246-289).
+
+Same constructor arguments (``args.device``, ``args.diffusion_steps``, ``args.is_train``, optional ``cfg_scale``),
+same ``generate(caption, m_lens, dim_pose, batch_size)`` -> list of (T, dim_pose) tensors, same checkpoint dict keys
+(``encoder``, ``ep``, ``total_it``, ``opt_encoder``).  The training loop (forward/backward/update/train) is out of
+scope for this build and raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from .diffusion import GaussianDiffusion, LossType, ModelMeanType, ModelVarType, get_named_beta_schedule
+
+
+class DDPMTrainer(object):
+    def __init__(self, args, encoder):
+        self.opt = args
+        self.device = args.device
+        self.encoder = encoder
+        self.diffusion_steps = args.diffusion_steps
+        betas = get_named_beta_schedule("linear", self.diffusion_steps)
+        self.diffusion = GaussianDiffusion(betas=betas, model_mean_type=ModelMeanType.EPSILON,
+                                           model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
+        self.sampler_name = "uniform"
+        self.to(self.device)
+        self.cfg_scale = getattr(args, "cfg_scale", 7.5)
+
+    def _model(self):
+        return self.encoder.module if hasattr(self.encoder, "module") else self.encoder
+
+    def to(self, device):
+        self._model().to(device)
+
+    def train_mode(self):
+        self._model().train()
+
+    def eval_mode(self):
+        self._model().eval()
+
+    @torch.no_grad()
+    def generate_batch(self, caption, m_lens, dim_pose, *, noise=None, step_noise=None, progress=True):
+        m = self._model()
+        xf_proj, xf_out = m.encode_text(caption, self.device)
+        m_lens = torch.as_tensor(m_lens)
+        T = min(int(m_lens.max()), m.num_frames)
+        B = len(caption)
+        return self.diffusion.p_sample_loop_with_cfg(
+            m, (B, T, dim_pose), clip_denoised=False, progress=progress, noise=noise, step_noise=step_noise,
+            model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out, "length": m_lens, "text": caption},
+            cfg_scale=self.cfg_scale)
+
+    @torch.no_grad()
+    def generate(self, caption, m_lens, dim_pose, batch_size=8, *, progress=False):
+        N = len(caption)
+        self.eval_mode()
+        all_output = []
+        cur = 0
+        while cur < N:
+            end = min(cur + batch_size, N)
+            out = self.generate_batch(caption[cur:end], m_lens[cur:end], dim_pose, progress=progress)
+            all_output.extend(out[i] for i in range(out.shape[0]))
+            cur += batch_size
+        return all_output
+
+    def save(self, file_name, ep, total_it):
+        state = {"opt_encoder": getattr(self, "opt_encoder_state", {}), "ep": ep, "total_it": total_it,
+                 "encoder": self._model().state_dict()}
+        torch.save(state, file_name)
+
+    def load(self, model_dir):
+        ckpt = torch.load(model_dir, map_location=self.device)
+        self._model().load_state_dict(ckpt["encoder"], strict=False)
+        return ckpt["ep"], ckpt.get("total_it", 0)
+
+    def train(self, *a, **k):
+        raise NotImplementedError("training is outside this build's scope (SURVEY.md §8f): only the sampling API "
+                                  "of DDPMTrainer is provided")
+
+    forward = backward_G = update = train
