@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising-steps/sec of the CFG DDPM sampling step (BASELINE.json configs[1]:
+model_size=small, 8 experts, B=32 per GPU, T=196, 263-d, 1000-step schedule, bf16 MFMA).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = the whole hot path over one batch: cond+uncond rows (2B) through the denoiser, guidance on pred_xstart,
+posterior update, noise.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # name: (ctor kwargs, algorithmic FLOP per forward at B=32,T=196,N=28 from SURVEY.md §8d, MoE share)
+    "small": (dict(latent_dim=512, ff_size=1024, num_layers=4, num_heads=4, text_latent_dim=256, moe_num_experts=8,
+                   model_size="small"), 0.9012e12, 0.338e12),
+    "big": (dict(latent_dim=512, ff_size=1024, num_layers=4, num_heads=4, text_latent_dim=256, moe_num_experts=8,
+                 model_size="big"), 3.5926e12, 1.349e12),
+}
+PEAK = {1: 2.5e15, 3: 2.5e15 / 3}  # dense bf16 MFMA; the bf16x3 mode issues 3 MFMAs per product
+
+
+def build_model(cfg_name, device, precision, B, T, N, seed=0):
+    T_ = importlib.import_module("motiondiffusion-moe_amd.transformer")
+    synth = importlib.import_module("motiondiffusion-moe_amd.synth")
+    kw, _, _ = CONFIGS[cfg_name]
+    m = T_.MotionTransformer(263, num_frames=196, precision=precision, **kw)
+    sd = synth.synth_state_dict(m._layout, seed)
+    m.load_state_dict(sd, strict=True)
+    D, Dt, L = m.latent_dim, m.text_latent_dim, m.num_layers
+    eph = synth.synth_ephemerals(D, Dt, L, 7)
+    proj = synth.synth_projections(D // m.num_heads, L, 7)
+    m.set_ephemerals(eph), m.set_projections(proj)
+    x, _, length, xf_proj, xf_out = synth.synth_inputs(B, T, 263, N, Dt, seed, min_len=40)
+    xo_u = synth.uniform_pm1((1, N, Dt), "in.uncond", seed) * (3.0 ** 0.5)
+    m = m.to(device).eval()
+    m.set_uncond_embedding(xo_u.mean(1).to(device), xo_u.to(device))
+    host = dict(sd=sd, eph={n: (w, b) for n, w, b in eph}, proj=dict(proj), xo_u=xo_u,
+                mcfg=dict(latent_dim=D, num_heads=m.num_heads, num_layers=L, moe_num_experts=m.moe_num_experts))
+    return m, (x, length, xf_proj, xf_out), host
+
+
+def cpu_baseline(host, inputs, steps_total, cfg_scale):
+    """The oracle (CPU restatement, pinned to the reference by golden vectors) timed on this host: one CFG step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import denoiser_ref as R
+    import diffusion_ref as DR
+    x, length, xf_proj, xf_out = inputs
+    B = x.shape[0]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    xo_u = host["xo_u"].expand(B, -1, -1).contiguous()
+    xp_u = xo_u.mean(1)
+    tb = DR.Tables(DR.linear_betas(steps_total))
+    t = steps_total - 1
+    tt = torch.full((B,), t, dtype=torch.int64)
+
+    def fwd(xx, cond, rows=B):
+        xp, xo = (xf_proj, xf_out) if cond else (xp_u, xo_u)
+        return R.denoiser_forward(host["sd"], host["mcfg"], xx[:rows], tt[:rows], length[:rows], xp[:rows], xo[:rows],
+                                  host["eph"], host["proj"])
+
+    with torch.no_grad():
+        fwd(x, True, rows=2)  # page in weights / warm the thread pool
+        t0 = time.perf_counter()
+        DR.cfg_step(tb, t, x, fwd(x, True), fwd(x, False), torch.zeros_like(x), cfg_scale)
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+            "sample": f"1 CFG step (2 forwards, B={B}, T={x.shape[1]}) of the torch-CPU oracle, fp32, {dt:.1f} s"}
+
+
+def time_block(fn, iters=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def moe_block_rate(m, B2, T, precision):
+    """HIP-event timing of the MoE FFN block (router + grouped expert GEMMs + combine/stylization) alone, on the
+    stream it is launched on; algorithmic FLOP = 16*M*D*F + 4*M*D*E + style at M = B2*T rows."""
+    import ctypes as C
+    L = importlib.import_module("motiondiffusion-moe_amd._lib")
+    pm = m.pack()
+    D, F_, E = m.latent_dim, m.ff_size, m.moe_num_experts
+    dev = m.device
+    M = B2 * T
+    h = torch.randn(B2, T, D, device=dev)
+    sc = torch.randn(4, B2, 2 * D, device=dev) * 0.1
+    ln = torch.full((B2,), T, dtype=torch.int32, device=dev)
+    out = torch.empty_like(h)
+    ws = m._workspace(B2, T, 28)
+    layer = m.num_layers  # first full-scale layer
+
+    def run():
+        L.check(L.lib().mdm_block_forward(C.byref(pm.model), C.c_int32(layer), C.c_int32(L.BLOCK_MOE), C.c_void_p(0),
+                                          C.c_void_p(h.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(ln.data_ptr()),
+                                          C.c_int32(B2), C.c_int32(T), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                          C.c_int64(ws.numel()), C.c_void_p(0), C.c_int32(precision), C.c_void_p(L.stream_ptr())))
+
+    saved = {k: v.clone() for k, v in m.moe_buffers().items()}
+    dt = time_block(run)
+    for k, v in saved.items():
+        m.moe_buffers()[k].copy_(v)
+    flop = 16.0 * M * D * F_ + 4.0 * M * D * E + 2.0 * M * D * D
+    return dt, flop
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="small", choices=list(CONFIGS))
+    ap.add_argument("--precision", type=int, default=1, choices=[1, 3], help="1 = bf16 MFMA, 3 = bf16x3 fp32-grade")
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
+    ap.add_argument("--frames", type=int, default=196)
+    ap.add_argument("--schedule", type=int, default=1000)
+    ap.add_argument("--cfg-scale", type=float, default=7.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the denoising path runs on hand-written HIP kernels only")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    D_ = importlib.import_module("motiondiffusion-moe_amd.diffusion")
+    dmod = importlib.import_module("motiondiffusion-moe_amd.dist")
+
+    B, T, N = a.batch, a.frames, 28
+    m, inputs, host = build_model(a.config, dev, a.precision, B, T, N, seed=0)
+    x, length, xf_proj, xf_out = inputs
+    diff = D_.GaussianDiffusion(betas=D_.get_named_beta_schedule("linear", a.schedule),
+                                model_mean_type=D_.ModelMeanType.EPSILON, model_var_type=D_.ModelVarType.FIXED_SMALL,
+                                loss_type=D_.LossType.MSE)
+    kw = {"xf_proj": xf_proj.to(dev), "xf_out": xf_out.to(dev), "length": length.to(dev), "text": ["synthetic"] * B}
+    r = diff._runner(m, (B, T, 263), kw, dev, "cfg", a.cfg_scale, 0.0, False, not a.no_graph)
+    r._prepare()
+    if r.use_graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            r._step(True)
+        r.graph = g
+    # world-size independent x_T: drawn for the global batch, sliced per rank
+    lo, hi = dmod.shard_range(B * world, rank, world)
+    x_T, _ = dmod.global_noise((B * world, T, 263), seed=1234)
+    r.xx[:B].copy_(x_T[lo:hi].to(dev))
+    r.t_dev.fill_(a.schedule - 1)
+
+    def one_step():
+        r.noise.normal_()
+        if r.graph is not None:
+            r.graph.replay()
+        else:
+            r._step(True)
+
+    for _ in range(a.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    # the path's single collective: gather the motion tensor of every shard (RCCL over xGMI)
+    final = dmod.all_gather_ragged(r.xx[:B].clone(), B * world)
+    assert final.shape[0] == B * world and bool(torch.isfinite(final).all())
+
+    if rank == 0:
+        _, flop_fwd, flop_moe = CONFIGS[a.config]
+        scale = (B / 32.0) * (T / 196.0)
+        flop_step = 2.0 * flop_fwd * scale  # cond + uncond forwards
+        ms = dt / a.steps * 1e3
+        steps_per_s = a.steps / dt
+        value = steps_per_s * world * (B / 32.0)
+        achieved = flop_step / (dt / a.steps)
+        moe_dt, moe_flop = moe_block_rate(m, 2 * B, T, a.precision)
+        line = {
+            "metric": "denoising-steps/sec (B=32, T=196, 263-d, 8 experts)", "value": round(value, 3),
+            "unit": "denoising-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.precision == 1 else "bf16x3(fp32-grade)", "data": "synthetic",
+            "config": {"workload": f"configs[1]: model_size={a.config}, num_experts=8, B={B}/GPU, T={T}, "
+                                   f"{a.schedule}-step DDPM with CFG {a.cfg_scale} (cond+uncond batched as {2 * B} rows), "
+                                   f"N_text={N}, hipGraph={'on' if r.graph is not None else 'off'}",
+                       "global_batch": B * world, "parallelism": f"batch-shard x{world}, weights replicated"},
+            "sample_steps_per_s": round(steps_per_s * B * world, 1),
+            "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK[a.precision] / 1e12,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.precision], 4), "traffic": None,
+                         "what": "whole step: algorithmic FLOP of 2 forwards / wall time per step",
+                         "moe_ffn_block": {"achieved": round(moe_flop / moe_dt / 1e12, 2), "us": round(moe_dt * 1e6, 1),
+                                           "frac": round(moe_flop / moe_dt / PEAK[a.precision], 4),
+                                           "rows": 2 * B * T, "timed_with": "HIP events on the launch stream"}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host, inputs, a.schedule, a.cfg_scale)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

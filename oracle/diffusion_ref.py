@@ -41,6 +41,39 @@ class Tables:
         return float(np.float32(arr[t]))
 
 
+def cfg_step(tb: Tables, t: int, x, eps_c, eps_u, noise, cfg_scale: float, clip: bool = False):
+    """One p_sample_with_cfg update given the two model outputs (:1065-1096); eps_u None = unguided p_sample."""
+    a = torch.tensor(tb.f32(tb.sqrt_recip_acp, t))
+    b = torch.tensor(tb.f32(tb.sqrt_recipm1_acp, t))
+    x0 = a * x - b * eps_c
+    if clip:
+        x0 = x0.clamp(-1, 1)
+    if eps_u is not None:
+        x0_u = a * x - b * eps_u
+        if clip:
+            x0_u = x0_u.clamp(-1, 1)
+        x0 = x0_u + cfg_scale * (x0 - x0_u)
+    mean = torch.tensor(tb.f32(tb.coef1, t)) * x0 + torch.tensor(tb.f32(tb.coef2, t)) * x
+    nz = 0.0 if t == 0 else 1.0
+    return mean + nz * torch.exp(0.5 * torch.tensor(tb.f32(tb.post_logvar_clipped, t))) * noise, x0
+
+
+def ddim_step(tb: Tables, t: int, x, eps_in, noise, eta: float, clip: bool = True):
+    """One ddim_sample update given the model output (:714-742)."""
+    a = torch.tensor(tb.f32(tb.sqrt_recip_acp, t))
+    b = torch.tensor(tb.f32(tb.sqrt_recipm1_acp, t))
+    x0 = a * x - b * eps_in
+    if clip:
+        x0 = x0.clamp(-1, 1)
+    eps = (a * x - x0) / b
+    ab = torch.tensor(tb.f32(tb.acp, t))
+    abp = torch.tensor(tb.f32(tb.acp_prev, t))
+    sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+    mean = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
+    nz = 0.0 if t == 0 else 1.0
+    return mean + nz * sigma * noise, x0
+
+
 def cfg_ddpm_loop(model: Callable, tb: Tables, x_T: torch.Tensor, step_noise: List[torch.Tensor],
                   cfg_scale: float = 7.5, keep: Optional[list] = None) -> torch.Tensor:
     """p_sample_loop_with_cfg with clip_denoised=False (as the trainer calls it, ddpm_trainer.py:161-173).
@@ -49,14 +82,7 @@ def cfg_ddpm_loop(model: Callable, tb: Tables, x_T: torch.Tensor, step_noise: Li
     B = x.shape[0]
     for i, t in enumerate(reversed(range(tb.num_steps))):
         tt = torch.full((B,), t, dtype=torch.int64)
-        a = torch.tensor(tb.f32(tb.sqrt_recip_acp, t))
-        b = torch.tensor(tb.f32(tb.sqrt_recipm1_acp, t))
-        x0_c = a * x - b * model(x, tt, True)
-        x0_u = a * x - b * model(x, tt, False)
-        x0 = x0_u + cfg_scale * (x0_c - x0_u)
-        mean = torch.tensor(tb.f32(tb.coef1, t)) * x0 + torch.tensor(tb.f32(tb.coef2, t)) * x
-        nz = 0.0 if t == 0 else 1.0
-        x = mean + nz * torch.exp(0.5 * torch.tensor(tb.f32(tb.post_logvar_clipped, t))) * step_noise[i]
+        x, _ = cfg_step(tb, t, x, model(x, tt, True), model(x, tt, False), step_noise[i], cfg_scale, clip=False)
         if keep is not None:
             keep.append(x.clone())
     return x
@@ -69,18 +95,7 @@ def ddim_loop(model: Callable, tb: Tables, x_T: torch.Tensor, step_noise: List[t
     B = x.shape[0]
     for i, t in enumerate(reversed(range(tb.num_steps))):
         tt = torch.full((B,), t, dtype=torch.int64)
-        a = torch.tensor(tb.f32(tb.sqrt_recip_acp, t))
-        b = torch.tensor(tb.f32(tb.sqrt_recipm1_acp, t))
-        x0 = a * x - b * model(x, tt, cond)
-        if clip_denoised:
-            x0 = x0.clamp(-1, 1)
-        eps = (a * x - x0) / b
-        ab = torch.tensor(tb.f32(tb.acp, t))
-        abp = torch.tensor(tb.f32(tb.acp_prev, t))
-        sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
-        mean = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
-        nz = 0.0 if t == 0 else 1.0
-        x = mean + nz * sigma * step_noise[i]
+        x, _ = ddim_step(tb, t, x, model(x, tt, cond), step_noise[i], eta, clip_denoised)
         if keep is not None:
             keep.append(x.clone())
     return x
