@@ -50,8 +50,9 @@ typedef struct MdmGemmDesc {
   const int32_t* goff; /* grouped mode: row ranges [goff[g], goff[g+1]) use W + g*W.bs1, bias + g*bias_bs */
   int32_t ngroups;
   int32_t act;
-  float* C;
+  float* C;       /* fp32 output (may be NULL when C16 is set) */
   int64_t ldc, c_bs1, c_bs2;
+  uint16_t* C16;  /* optional bf16 copy of the output (same ldc / batch strides, in elements) */
   const float* bias;
   int64_t bias_bs;
   float alpha, out_scale, r1_scale;
@@ -189,6 +190,9 @@ int mdm_ddim_step(const float* x, const float* eps, const float* noise, int64_t 
 int mdm_xattn_gate(const float* gate, const float* adaptive_gate, int32_t D, float* out, void* stream);
 int mdm_fill_i64(int64_t* dst, int64_t n, const int32_t* src_dev, void* stream);
 int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
+
+/* tuning knob for benchmarks: selects the (BK, stages) variant of the bf16 throughput GEMM (0 = default) */
+int mdm_set_gemm_variant(int variant);
 
 const char* mdm_version(void);
 

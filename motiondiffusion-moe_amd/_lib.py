@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("A", Operand), ("W", Operand), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("batch", C.c_int32), ("nb2", C.c_int32), ("goff", C.c_void_p), ("ngroups", C.c_int32),
                 ("act", C.c_int32), ("C", C.c_void_p), ("ldc", C.c_int64), ("c_bs1", C.c_int64),
-                ("c_bs2", C.c_int64), ("bias", C.c_void_p), ("bias_bs", C.c_int64), ("alpha", C.c_float),
+                ("c_bs2", C.c_int64), ("C16", C.c_void_p), ("bias", C.c_void_p), ("bias_bs", C.c_int64), ("alpha", C.c_float),
                 ("out_scale", C.c_float), ("r1_scale", C.c_float), ("r1_mod", C.c_int32),
                 ("colscale", C.c_void_p), ("rowscale", C.c_void_p), ("R1", C.c_void_p), ("ldr1", C.c_int64),
                 ("R2", C.c_void_p), ("ldr2", C.c_int64), ("feat_len", C.c_void_p), ("feat_S", C.c_int32),
@@ -112,7 +112,7 @@ def lib():
 # every symbol include/mdm_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mdm_version", "mdm_gemm", "mdm_pack_bf16", "mdm_workspace_bytes", "mdm_text_cache_build",
            "mdm_denoiser_forward", "mdm_block_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
-           "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32"]
+           "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant"]
 
 
 def check(status: int, what: str = "mdm call"):

@@ -23,7 +23,14 @@ __global__ void pack_bf16_kernel(const float* __restrict__ src, int64_t ld_src, 
 }  // namespace
 }  // namespace mdm
 
+namespace mdm { extern int g_bf16_variant; }
+
 extern "C" {
+
+int mdm_set_gemm_variant(int v) {
+  mdm::g_bf16_variant = v;
+  return MDM_OK;
+}
 
 const char* mdm_version(void) { return "mdm_hip 0.1 (gfx950)"; }
 

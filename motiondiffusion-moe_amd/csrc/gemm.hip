@@ -171,7 +171,7 @@ struct TileLoader {
   }
 };
 
-template <int AK, int WK, int NPL>
+template <int AK, int WK, int NPL, int ACT>
 __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int STAGE = 2 * NPL * PLANE;  // A planes then W planes
@@ -263,65 +263,100 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-  float* C = g.C + offC;
-  const float* bias = g.bias ? g.bias + offB : nullptr;
+  // epilogue: C/D map of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.  Loads are hoisted ahead of the
+  // stores and pointers restrict-qualified (outputs never alias bias / residual inputs).
+  float* __restrict__ C = g.C ? g.C + offC : nullptr;
+  uint16_t* __restrict__ C16 = g.C16 ? g.C16 + offC : nullptr;
+  const float* __restrict__ bias = g.bias ? g.bias + offB : nullptr;
+  const float* __restrict__ colscale = g.colscale;
+  const float* __restrict__ R1 = g.R1;
+  const float* __restrict__ R2 = g.R2;
+  float bv[4], cv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = nt * BN + wn * 64 + j * 16 + (lane & 15);
-    if (n >= g.N) continue;
-    const float bv = bias ? bias[n] : 0.f;
-    const float cs = g.colscale ? g.colscale[n] : 1.f;
+    const int nn = n < g.N ? n : g.N - 1;
+    bv[j] = bias ? bias[nn] : 0.f;
+    cv[j] = g.out_scale * (colscale ? colscale[nn] : 1.f);
+  }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i) {
+    float q1[4][4], q2[4][4], rs[4];
+    bool km[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (m >= row_end) continue;
-        float v = g.alpha * (acc[i][j][r] + bv);
-        if (g.act == ACT_GELU) {
+    for (int r = 0; r < 4; ++r) {
+      const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+      const bool ok = m < row_end;
+      rs[r] = (ok && g.rowscale) ? g.rowscale[m] : 1.f;
+      km[r] = false;
+      if (ok && ACT == ACT_FEAT && g.feat_len) {
+        const int tok = m / g.feat_rpt, slot = m - tok * g.feat_rpt;
+        if (slot >= g.feat_kslot) {
+          const int bb = tok / g.feat_S, t = tok - bb * g.feat_S;
+          km[r] = t >= g.feat_len[bb];
+        }
+      }
+      const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nt * BN + wn * 64 + j * 16 + (lane & 15);
+        const bool in = ok && n < g.N;
+        q1[r][j] = (in && R1) ? R1[mr * g.ldr1 + n] : 0.f;
+        q2[r][j] = (in && R2) ? R2[(int64_t)m * g.ldr2 + n] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = row0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= row_end) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nt * BN + wn * 64 + j * 16 + (lane & 15);
+        if (n >= g.N) continue;
+        float v = g.alpha * (acc[i][j][r] + bv[j]);
+        if constexpr (ACT == ACT_GELU) {
           v = gelu_erf(v);
-        } else if (g.act == ACT_SILU) {
+        } else if constexpr (ACT == ACT_SILU) {
           v = silu(v);
-        } else if (g.act == ACT_FEAT) {
-          v = 0.1f * expf(fminf(fmaxf(v, -15.f), 15.f));
-          if (g.feat_len) {
-            const int tok = m / g.feat_rpt, slot = m - tok * g.feat_rpt;
-            if (slot >= g.feat_kslot) {
-              const int bb = tok / g.feat_S, t = tok - bb * g.feat_S;
-              if (t >= g.feat_len[bb]) v = 0.f;
-            }
-          }
+        } else if constexpr (ACT == ACT_FEAT) {
+          v = km[r] ? 0.f : 0.1f * expf(fminf(fmaxf(v, -15.f), 15.f));
         }
-        v *= g.out_scale * cs;
-        if (g.rowscale) v *= g.rowscale[m];
-        if (g.R1) {
-          const int mr = g.r1_mod ? (m % g.r1_mod) : m;
-          v += g.r1_scale * g.R1[(int64_t)mr * g.ldr1 + n];
-        }
-        if (g.R2) v += g.R2[(int64_t)m * g.ldr2 + n];
-        C[(int64_t)m * g.ldc + n] = v;
+        v = v * (cv[j] * rs[r]) + g.r1_scale * q1[r][j] + q2[r][j];
+        if (C) C[(int64_t)m * g.ldc + n] = v;
+        if (C16) C16[(int64_t)m * g.ldc + n] = (uint16_t)(pack_bf16(v, 0.f) & 0xffff);
       }
     }
   }
 }
 
-template <int AK, int WK>
-int launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
+template <int AK, int WK, int ACT>
+int launch_act(const GemmArgs& a, dim3 grid, hipStream_t s) {
   if (a.precision == 3) {
-    hipLaunchKernelGGL((gemm_kernel<AK, WK, 2>), grid, dim3(NT), 2 * 2 * 2 * PLANE, s, a);
+    hipLaunchKernelGGL((gemm_kernel<AK, WK, 2, ACT>), grid, dim3(NT), 2 * 2 * 2 * PLANE, s, a);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<AK, WK, 1>), grid, dim3(NT), 2 * 2 * 1 * PLANE, s, a);
+    hipLaunchKernelGGL((gemm_kernel<AK, WK, 1, ACT>), grid, dim3(NT), 2 * 2 * 1 * PLANE, s, a);
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
+}
+
+template <int AK, int WK, bool ALL_ACTS>
+int launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  if (a.act == ACT_NONE) return launch_act<AK, WK, ACT_NONE>(a, grid, s);
+  if constexpr (ALL_ACTS) {
+    if (a.act == ACT_GELU) return launch_act<AK, WK, ACT_GELU>(a, grid, s);
+    if (a.act == ACT_SILU) return launch_act<AK, WK, ACT_SILU>(a, grid, s);
+    if (a.act == ACT_FEAT) return launch_act<AK, WK, ACT_FEAT>(a, grid, s);
+  }
+  return MDM_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
 int gemm(const GemmArgs& a, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return MDM_OK;
-  if (a.K <= 0 || !a.A.p || !a.W.p || !a.C) return MDM_ERR_ARG;
+  if (a.K <= 0 || !a.A.p || !a.W.p || (!a.C && !a.C16)) return MDM_ERR_ARG;
+  if (a.A.kind == OP_BF16_ROW) return gemm_bf16(a, stream);  // bf16 activations: throughput kernel (gemm2.hip)
   if (a.precision != 1 && a.precision != 3) return MDM_ERR_ARG;
   if (a.W.kind == OP_BF16_ROW) {
     if ((a.W.ld & 31) || (((uintptr_t)a.W.p) & 15) || (a.W.bs1 & 7) || (a.W.bs2 & 7)) return MDM_ERR_ARG;
@@ -334,10 +369,10 @@ int gemm(const GemmArgs& a, hipStream_t stream) {
   const int tn = (a.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);
   const int ak = a.A.kind, wk = a.W.kind;
-  if (ak == OP_F32_ROW && wk == OP_BF16_ROW) return launch<OP_F32_ROW, OP_BF16_ROW>(a, grid, stream);
-  if (ak == OP_F32_ROW && wk == OP_F32_ROW) return launch<OP_F32_ROW, OP_F32_ROW>(a, grid, stream);
-  if (ak == OP_F32_ROW && wk == OP_F32_KSTRIDE) return launch<OP_F32_ROW, OP_F32_KSTRIDE>(a, grid, stream);
-  if (ak == OP_F32_KSTRIDE && wk == OP_F32_KSTRIDE) return launch<OP_F32_KSTRIDE, OP_F32_KSTRIDE>(a, grid, stream);
+  if (ak == OP_F32_ROW && wk == OP_BF16_ROW) return launch<OP_F32_ROW, OP_BF16_ROW, true>(a, grid, stream);
+  if (ak == OP_F32_ROW && wk == OP_F32_ROW) return launch<OP_F32_ROW, OP_F32_ROW, false>(a, grid, stream);
+  if (ak == OP_F32_ROW && wk == OP_F32_KSTRIDE) return launch<OP_F32_ROW, OP_F32_KSTRIDE, false>(a, grid, stream);
+  if (ak == OP_F32_KSTRIDE && wk == OP_F32_KSTRIDE) return launch<OP_F32_KSTRIDE, OP_F32_KSTRIDE, false>(a, grid, stream);
   return MDM_ERR_UNSUPPORTED;
 }
 

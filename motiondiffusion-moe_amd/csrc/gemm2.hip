@@ -1,0 +1,285 @@
+// Throughput GEMM for gfx950: bf16 activations x bf16 weights, fp32 accumulate.
+//   * both operands stream global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no conversion): each
+//     wave-instruction lands 8 rows x 128 B; the LDS image stays lane-linear and the 16-B chunks of a row are
+//     XOR-swizzled on the SOURCE address (chunk ^ (row & 7)), the same involution is applied on the fragment read,
+//     which makes every ds_read_b128 of a 16x16x32 fragment conflict-free;
+//   * 128x128x64 tile, 4 waves (2x2), NSTAGE-deep ring, one barrier per K-tile, 2 blocks per CU;
+//   * MFMA operands are swapped (W fragment as A, activation fragment as B) so each lane ends up with 4 CONSECUTIVE
+//     output columns of one row: 16-byte stores / residual loads in the epilogue instead of 4-byte ones.
+// Row gather (MoE expert inputs), grouped and batched modes as in gemm.hip.
+#include "gemm.h"
+
+namespace mdm {
+namespace {
+
+constexpr int BM = 128, BN = 128, NT = 256;
+
+typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void glds16(const void* g, uint8_t* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS image of one operand tile: 128 rows x (2*BK) bytes, 16-B chunks swizzled so that the ds_read_b128 of a
+// 16x16x32 fragment (16 rows x one chunk per 16-lane group) is conflict-free:
+//   BK = 64 (128-B rows, 8 chunks):  phys = chunk ^ (row & 7)
+//   BK = 32 ( 64-B rows, 4 chunks):  phys = (chunk + 2 * (row >> 2)) & 3
+template <int BK>
+__device__ __forceinline__ int chunk_phys(int row, int c) {
+  if constexpr (BK == 64) return c ^ (row & 7);
+  return (c + 2 * (row >> 2)) & 3;
+}
+template <int BK>
+__device__ __forceinline__ int chunk_logical(int row, int phys) {
+  if constexpr (BK == 64) return phys ^ (row & 7);
+  return (phys - 2 * (row >> 2)) & 3;
+}
+
+template <int BK, int NSTAGE, int ACT>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
+  constexpr int ROWB = 2 * BK;             // bytes per LDS row
+  constexpr int TILE_B = BM * ROWB;        // bytes per operand per stage
+  constexpr int RPP = 1024 / ROWB;         // rows per 1-KiB LDS-DMA piece (8 or 16)
+  constexpr int PPW = BM / RPP / 4;        // pieces per wave per operand per stage (4 or 2)
+  constexpr int CPR = ROWB / 16;           // 16-B chunks per row
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  const int ntn = (g.N + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = tile % ntn, mt = tile / ntn;
+  int row0, row_end, grp = 0;
+  if (g.goff) {
+    int acc_t = 0, found = -1;
+    for (int e = 0; e < g.ngroups; ++e) {
+      const int b = g.goff[e], en = g.goff[e + 1];
+      const int t = (en - b + BM - 1) / BM;
+      if (mt < acc_t + t) {
+        found = e, row0 = b + (mt - acc_t) * BM, row_end = en;
+        break;
+      }
+      acc_t += t;
+    }
+    if (found < 0) return;
+    grp = found;
+  } else {
+    row0 = mt * BM, row_end = g.M;
+    if (row0 >= row_end) return;
+  }
+  const int z = blockIdx.z, z1 = z / g.nb2, z2 = z % g.nb2;
+  const int64_t offA = (int64_t)z1 * g.A.bs1 + (int64_t)z2 * g.A.bs2;
+  const int64_t offW = g.goff ? (int64_t)grp * g.W.bs1 : (int64_t)z1 * g.W.bs1 + (int64_t)z2 * g.W.bs2;
+  const int64_t offC = (int64_t)z1 * g.c_bs1 + (int64_t)z2 * g.c_bs2;
+  const int64_t offB = g.goff ? (int64_t)grp * g.bias_bs : (int64_t)z * g.bias_bs;
+
+  // per-lane source rows of this wave's LDS-DMA pieces (RPP rows x ROWB bytes each); rows past the edge are
+  // clamped to a valid row (their products are discarded in the epilogue): pad, don't mask
+  const int sub = lane / CPR;  // row inside the piece
+  const uint16_t* pa[PPW];
+  const uint16_t* pw[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int tr = (wid * PPW + i) * RPP + sub;  // row inside the tile
+    const int koff = chunk_logical<BK>(tr, lane % CPR) * 8;
+    int r = row0 + tr;
+    r = r < row_end ? r : row_end - 1;
+    const int64_t src = g.A.gather ? (int64_t)g.A.gather[r] : (int64_t)r;
+    pa[i] = (const uint16_t*)g.A.p + offA + src * g.A.ld + koff;
+    int n = nt * BN + tr;
+    n = n < g.N ? n : g.N - 1;
+    pw[i] = (const uint16_t*)g.W.p + offW + (int64_t)n * g.W.ld + koff;
+  }
+  auto stage = [&](int kt, int buf) {
+    uint8_t* sa = smem + buf * 2 * TILE_B + wid * PPW * 1024;
+    uint8_t* sw = sa + TILE_B;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(pa[i] + k0, sa + i * 1024);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(pw[i] + k0, sw + i * 1024);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, s);
+
+  constexpr int PIECES = 2 * PPW;  // LDS-DMA instructions per wave per K-tile
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once each wave's pieces for it have: wait for all but the younger tiles, then barrier
+    const int younger = min(NSTAGE - 2, nk - 1 - kt);
+    if (younger >= 2) {
+      wait_vm<2 * PIECES>();
+    } else if (younger == 1) {
+      wait_vm<PIECES>();
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+    const uint8_t* sa = smem + (kt % NSTAGE) * 2 * TILE_B;
+    const uint8_t* sw = sa + TILE_B;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      frag_t a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + frow, rb = wn * 64 + i * 16 + frow;
+        a[i] = *(const frag_t*)(sa + ra * ROWB + (chunk_phys<BK>(ra, ks * 4 + fq) << 4));
+        b[i] = *(const frag_t*)(sw + rb * ROWB + (chunk_phys<BK>(rb, ks * 4 + fq) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);  // D = W A^T: (n, m)
+    }
+  }
+
+  // epilogue.  D tile (j,i): lane holds n = nb + 4*(lane>>4) + r (r = 0..3) for m = mb + (lane & 15).
+  // All loads of a row are issued before its stores and the pointers are restrict-qualified: the outputs never
+  // alias bias / residual inputs, and a load that has to wait behind each store serialises the whole tile.
+  float* __restrict__ C = g.C ? g.C + offC : nullptr;
+  uint16_t* __restrict__ C16 = g.C16 ? g.C16 + offC : nullptr;
+  const float* __restrict__ bias = g.bias ? g.bias + offB : nullptr;
+  const float* __restrict__ colscale = g.colscale;
+  const float* __restrict__ R1 = g.R1;
+  const float* __restrict__ R2 = g.R2;
+  const bool vec = ((g.ldc & 3) == 0) && (!R1 || (g.ldr1 & 3) == 0) && (!R2 || (g.ldr2 & 3) == 0);
+  const int nbase = nt * BN + wn * 64 + fq * 4;
+  float bv[4][4], cv[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nbase + j * 16 + r;
+      const int nn = n < g.N ? n : g.N - 1;
+      bv[j][r] = bias ? bias[nn] : 0.f;
+      cv[j][r] = g.out_scale * (colscale ? colscale[nn] : 1.f);
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= row_end) continue;
+    const float rs = g.rowscale ? g.rowscale[m] : 1.f;
+    const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
+    bool keymask = false;
+    if (ACT == ACT_FEAT && g.feat_len) {
+      const int tok = m / g.feat_rpt, slot = m - tok * g.feat_rpt;
+      if (slot >= g.feat_kslot) {
+        const int bb = tok / g.feat_S, t = tok - bb * g.feat_S;
+        keymask = t >= g.feat_len[bb];
+      }
+    }
+    f32x4 q1[4], q2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nbase + j * 16;
+      q1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}, q2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (vec && n + 3 < g.N) {
+        if (R1) q1[j] = *(const f32x4*)(R1 + mr * g.ldr1 + n);
+        if (R2) q2[j] = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < g.N) {
+            if (R1) q1[j][r] = R1[mr * g.ldr1 + n + r];
+            if (R2) q2[j][r] = R2[(int64_t)m * g.ldr2 + n + r];
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nbase + j * 16;
+      if (n >= g.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = g.alpha * (acc[i][j][r] + bv[j][r]);
+        if constexpr (ACT == ACT_GELU) {
+          x = gelu_erf(x);
+        } else if constexpr (ACT == ACT_SILU) {
+          x = silu(x);
+        } else if constexpr (ACT == ACT_FEAT) {
+          x = keymask ? 0.f : 0.1f * expf(fminf(fmaxf(x, -15.f), 15.f));
+        }
+        v[r] = x * (cv[j][r] * rs) + g.r1_scale * q1[j][r] + q2[j][r];
+      }
+      if (vec && n + 3 < g.N) {
+        if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+        if (C16) *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= g.N) break;
+          if (C) C[(int64_t)m * g.ldc + n + r] = v[r];
+          if (C16) C16[(int64_t)m * g.ldc + n + r] = (uint16_t)(pack_bf16(v[r], 0.f) & 0xffff);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int g_bf16_variant = 0;  // tuning knob (mdm_set_gemm_variant): 0 = default
+
+bool gemm_bf16_eligible(const GemmArgs& a) {
+  return a.precision == 1 && a.A.kind == OP_BF16_ROW && a.W.kind == OP_BF16_ROW && a.K > 0 && (a.K % 64) == 0 &&
+         (a.A.ld % 8) == 0 && (a.W.ld % 8) == 0 && (a.A.bs1 % 8) == 0 && (a.A.bs2 % 8) == 0 &&
+         ((((uintptr_t)a.A.p) | ((uintptr_t)a.W.p)) & 15) == 0 && a.A.rpg == 0;
+}
+
+template <int BK, int NS, int ACT>
+static int launch_bf16_act(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+  constexpr int smem = NS * 2 * BM * 2 * BK;
+  static bool attr_set = false;
+  if (smem > 65536 && !attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BK, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess)
+      return MDM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<BK, NS, ACT>), grid, dim3(NT), smem, stream, a);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+template <int BK, int NS>
+static int launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+  switch (a.act) {
+    case ACT_NONE: return launch_bf16_act<BK, NS, ACT_NONE>(a, grid, stream);
+    case ACT_GELU: return launch_bf16_act<BK, NS, ACT_GELU>(a, grid, stream);
+    case ACT_SILU: return launch_bf16_act<BK, NS, ACT_SILU>(a, grid, stream);
+    case ACT_FEAT: return launch_bf16_act<BK, NS, ACT_FEAT>(a, grid, stream);
+    default: return MDM_ERR_ARG;
+  }
+}
+
+int gemm_bf16(const GemmArgs& a, hipStream_t stream) {
+  if (!gemm_bf16_eligible(a)) return MDM_ERR_UNSUPPORTED;
+  if (!a.C && !a.C16) return MDM_ERR_ARG;
+  const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
+  const int tn = (a.N + BN - 1) / BN;
+  dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);
+  switch (g_bf16_variant) {
+    case 3: return launch_bf16<32, 3>(a, grid, stream);
+    default: return launch_bf16<64, 2>(a, grid, stream);
+  }
+}
+
+}  // namespace mdm

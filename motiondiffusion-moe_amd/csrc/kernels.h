@@ -13,7 +13,8 @@ struct MoeGateParams {
   const float* ln_b[2];
   const float* gate_w[2];  // (E, D) fp32
   const float* gate_b[2];  // (E)
-  float* hn;               // (2, M, D) out: LN_b(x)
+  void* hn;                // (2, M, D) out: LN_b(x), fp32 or bf16
+  int hn_bf16;
   int* top_idx;            // (2, M, 2)
   float* top_val;          // (2, M, 2)
   int* hist;               // (2E) zeroed by moe_route
@@ -22,15 +23,17 @@ struct MoeGateParams {
   const int* forced_idx;   // optional (2, M, 2) injected routing (tests)
 };
 
-int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, float* y1, const float* w2,
-             const float* b2, float* y2, hipStream_t s);
+// y1/y2/out: fp32 tensors, or bf16 (uint16_t) when the matching *_bf flag is set
+int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, void* y1, int y1_bf, const float* w2,
+             const float* b2, void* y2, int y2_bf, hipStream_t s);
 int style_in(const float* x, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw,
-             const float* sb, const float* sc, const int* pos4, float* out, hipStream_t s);
+             const float* sb, const float* sc, const int* pos4, void* out, int out_bf, hipStream_t s);
+int to_bf16(const float* src, int64_t n, uint16_t* dst, hipStream_t s);
 int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, int* goff, int* cursor, int* perm,
               float* rowscale, int* pos4, hipStream_t s);
 int head_norm(float* qkv, int64_t M, int H, int dh, const float* w, const float* b, hipStream_t s);
-int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const float* w, const float* b, float* out,
-           hipStream_t s);
+int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const float* w, const float* b, void* out,
+           int out_bf, hipStream_t s);
 int head_softmax(float* q, int64_t units, int dh, hipStream_t s);
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
 int col_softmax(float* k, int B, int N, int D, hipStream_t s);

@@ -27,8 +27,10 @@ struct Bump {  // carve the caller's workspace; with base == nullptr it only mea
 };
 
 struct Work {
-  // token-major activations (M = B*T rows)
+  // token-major activations (M = B*T rows).  x?16 / h016: bf16 shadows of the fp32 residual stream, written by the
+  // producing GEMM's epilogue in the throughput mode so that the next GEMM streams bf16 straight into LDS.
   float *xa, *xb, *h0, *t1, *t2, *t3, *t4, *t5, *qkv, *phi, *kvt, *scr, *f1, *hn, *hid, *y2;
+  uint16_t *xa16, *xb16, *h016;
   int *top_idx, *perm, *pos4, *hist, *goff, *cursor, *len_low;
   float *top_val, *rowscale;
   // stem (B rows)
@@ -44,6 +46,7 @@ Work carve(const MdmModel& m, int B, int T, int N, void* ws) {
   const int64_t M = (int64_t)B * T, D = m.D, F = m.F, Te = 4 * D, nblk = 8 * m.L;
   const int dh = m.D / m.H;
   w.xa = b.take<float>(M * D), w.xb = b.take<float>(M * D), w.h0 = b.take<float>(M * D);
+  w.xa16 = b.take<uint16_t>(M * D), w.xb16 = b.take<uint16_t>(M * D), w.h016 = b.take<uint16_t>(M * D);
   w.t1 = b.take<float>(M * D), w.t2 = b.take<float>(M * D), w.t3 = b.take<float>(M * D);
   w.t4 = b.take<float>(M * D), w.t5 = b.take<float>(M * D);
   w.qkv = b.take<float>(M * 3 * D);
@@ -74,6 +77,7 @@ struct Ctx {
   const MdmModel* m;
   hipStream_t s;
   int prec;
+  bool bf;          // throughput mode (precision 1): GEMM-only tensors are kept in bf16
   int B, S, N;      // batch, frames at this scale, text tokens
   int64_t M;        // B*S
   const int* len;   // lengths at this scale
@@ -82,38 +86,72 @@ struct Ctx {
 
 inline Operand packed(const MdmPacked& p) { return op_bf16(p.hi, p.lo, p.ld); }
 
-// y = epilogue(x @ W^T) for a plain [M,K]x[N,K] Linear
-int linear(const Ctx& c, const float* x, int64_t M, int K, const MdmPacked& W, const float* bias, int N, float* out,
-           int act = ACT_NONE, float alpha = 1.f, float out_scale = 1.f, const float* R1 = nullptr, float r1_scale = 1.f,
-           const float* R2 = nullptr, const float* colscale = nullptr, int r1_mod = 0) {
+// a tensor that is fp32 in the fp32-grade mode and bf16 in the throughput mode, living in a float-sized buffer
+struct Act {
+  void* p;
+  bool bf;
+};
+inline Act act_of(const Ctx& c, float* buf) { return Act{buf, c.bf}; }
+inline Act act_f32(const float* buf) { return Act{(void*)buf, false}; }
+inline Act act_bf16(const uint16_t* buf) { return Act{(void*)buf, true}; }
+
+struct LinOpts {
+  int act = ACT_NONE;
+  float alpha = 1.f, out_scale = 1.f, r1_scale = 1.f;
+  const float* R1 = nullptr;
+  const float* R2 = nullptr;
+  const float* colscale = nullptr;
+  int r1_mod = 0;
+};
+
+// out32 / out16 = epilogue(A @ W^T) for a plain [M,K]x[N,K] Linear; either output may be null
+int linear(const Ctx& c, Act A, int64_t M, int K, const MdmPacked& W, const float* bias, int N, float* out32,
+           uint16_t* out16, const LinOpts& o = LinOpts()) {
   GemmArgs g = gemm_defaults(c.prec);
-  g.A = op_f32(x, K);
+  if (A.bf) {
+    g.A.p = A.p, g.A.ld = K, g.A.kind = OP_BF16_ROW;
+  } else {
+    g.A = op_f32((const float*)A.p, K);
+  }
   g.W = packed(W);
   g.M = (int)M, g.N = N, g.K = K;
-  g.C = out, g.ldc = N;
+  g.C = out32, g.C16 = out16, g.ldc = N;
   g.bias = bias;
-  g.act = act, g.alpha = alpha, g.out_scale = out_scale;
-  g.R1 = R1, g.ldr1 = N, g.r1_scale = r1_scale, g.r1_mod = r1_mod;
-  g.R2 = R2, g.ldr2 = N;
-  g.colscale = colscale;
+  g.act = o.act, g.alpha = o.alpha, g.out_scale = o.out_scale;
+  g.R1 = o.R1, g.ldr1 = N, g.r1_scale = o.r1_scale, g.r1_mod = o.r1_mod;
+  g.R2 = o.R2, g.ldr2 = N;
+  g.colscale = o.colscale;
+  if (A.bf && !gemm_bf16_eligible(g)) return MDM_ERR_UNSUPPORTED;
   return gemm(g, c.s);
+}
+// result typed like the mode: fp32 buffer in the fp32-grade mode, bf16 in the throughput mode
+int linear_to_act(const Ctx& c, Act A, int64_t M, int K, const MdmPacked& W, const float* bias, int N, float* buf,
+                  const LinOpts& o = LinOpts()) {
+  return linear(c, A, M, K, W, bias, N, c.bf ? nullptr : buf, c.bf ? (uint16_t*)buf : nullptr, o);
 }
 
 // out = resid + out_scale * colscale * Lin(SiLU(LN(a)(1+scale)+shift)) with a = [post-processed] src
 int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float* pw, const float* pb, const int* pos4,
-                const float* sc, float* tmp, const float* resid, float out_scale, const float* colscale, float* out) {
+                const float* sc, float* tmp, const float* resid, float out_scale, const float* colscale, float* out,
+                uint16_t* out16 = nullptr) {
   const int D = c.m->D;
-  MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, tmp, c.s));
-  return linear(c, tmp, c.M, D, st.out, st.out_b, D, out, ACT_NONE, 1.f, out_scale, resid, 1.f, nullptr, colscale);
+  MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, tmp, c.bf, c.s));
+  LinOpts o;
+  o.out_scale = out_scale, o.R1 = resid, o.colscale = colscale;
+  return linear(c, act_of(c, tmp), c.M, D, st.out, st.out_b, D, out, out16, o);
 }
 
 // PerformerSelfAttention (fast_attention.py:137-179): xn = pre_norm(x) already computed; out = x + 0.1*style(...)
-int performer(const Ctx& c, const MdmPerformer& p, const float* x, const float* xn, const float* sc, float* out) {
+int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const float* sc, float* out) {
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H, mf = dh;  // m = min(dh, 256) = dh for dh <= 256
   const Work& w = c.w;
   // q|k|v = 0.1 * (xn W^T + b)                                   (:145-157)
-  MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, w.qkv, ACT_NONE, 0.1f));
+  {
+    LinOpts o;
+    o.alpha = 0.1f;
+    MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, w.qkv, nullptr, o));
+  }
   // shared LN over head_dim, L2 normalise q,k                     (:44-55)
   MDM_TRY(head_norm(w.qkv, c.M, H, dh, p.hn_w, p.hn_b, c.s));
   // feature maps 0.1*exp(clamp(z P)), keys masked past length     (:58-74): rows = (token, slot<2H)
@@ -155,27 +193,35 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, const float* 
     MDM_TRY(gemm(g, c.s));
   }
   // same-t denominator, divide, LN over head_dim                   (:81-90) -> t4
-  MDM_TRY(den_ln(w.t2, w.phi, c.M, H, dh, p.hn_w, p.hn_b, w.t4, c.s));
+  MDM_TRY(den_ln(w.t2, w.phi, c.M, H, dh, p.hn_w, p.hn_b, w.t4, c.bf, c.s));
   // proj_out: Linear -> GELU -> Linear                             (:121-126,165)
-  MDM_TRY(linear(c, w.t4, c.M, D, p.proj0, p.proj0_b, D, w.t2, ACT_GELU));
-  MDM_TRY(linear(c, w.t2, c.M, D, p.proj3, p.proj3_b, D, w.t4));
+  {
+    LinOpts o;
+    o.act = ACT_GELU;
+    MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, p.proj0, p.proj0_b, D, w.t2, o));
+  }
+  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, p.proj3, p.proj3_b, D, w.t4, nullptr));
   // post_norm, normalize * sqrt(D), stylization, y = x + 0.1 * style (:169-178)
   return style_apply(c, p.style, w.t4, p.post_w, p.post_b, nullptr, sc, w.t2, x, 0.1f, nullptr, out);
 }
 
-// DualSelfAttentionBlock (fast_attention.py:208-226): x -> out.  Uses t1..t5.
-int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc4, float* out) {
+// DualSelfAttentionBlock (fast_attention.py:208-226): x -> out.  Uses t1..t5.  x16: bf16 shadow of x (throughput mode)
+int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* x16, const float* sc4, float* out) {
   const int D = c.m->D;
   const Work& w = c.w;
   const int64_t scs = (int64_t)c.B * 2 * D;
   // h = pre_norm(x) -> t1 ; local.pre_norm(h) -> t3
-  MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, l.local.pre_w, l.local.pre_b, w.t3, c.s));
-  MDM_TRY(performer(c, l.local, w.t1, w.t3, sc4 + 0 * scs, w.t5));  // local_out -> t5
-  MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, nullptr, nullptr, nullptr, c.s));
-  MDM_TRY(performer(c, l.global, w.t5, w.t3, sc4 + 1 * scs, w.t1));  // global_out -> t1
+  MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, 0, l.local.pre_w, l.local.pre_b, w.t3, c.bf, c.s));
+  MDM_TRY(performer(c, l.local, w.t1, act_of(c, w.t3), sc4 + 0 * scs, w.t5));  // local_out -> t5
+  MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  MDM_TRY(performer(c, l.global, w.t5, act_of(c, w.t3), sc4 + 1 * scs, w.t1));  // global_out -> t1
   // skip = GELU(Lin(x)); out = post_norm(skip + 0.1 * global)      (:219-225)
-  MDM_TRY(linear(c, x, c.M, D, l.skip, l.skip_b, D, w.t3, ACT_GELU, 1.f, 1.f, w.t1, 0.1f));
-  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, nullptr, nullptr, nullptr, c.s);
+  {
+    LinOpts o;
+    o.act = ACT_GELU, o.R1 = w.t1, o.r1_scale = 0.1f;
+    MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.skip, l.skip_b, D, w.t3, nullptr, o));
+  }
+  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, 0, nullptr, nullptr, nullptr, 0, c.s);
 }
 
 // GatedCrossAttention (fast_attention.py:242-272): out = x + sigmoid(gate)*sigmoid(adaptive)*style(softmax(q) A)
@@ -183,8 +229,8 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H;
   const Work& w = c.w;
-  MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, nullptr, nullptr, nullptr, c.s));
-  MDM_TRY(linear(c, w.t2, c.M, D, l.ca_q, l.ca_q_b, D, w.t3));
+  MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, w.t3, nullptr));
   MDM_TRY(head_softmax(w.t3, c.M * H, dh, c.s));  // softmax over head_dim (:248)
   {
     GemmArgs g = gemm_defaults(c.prec);  // y[b,s,h,:] = q[b,s,h,:] A[b,h]  (:253), W = A^T rows
@@ -201,7 +247,8 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
 }
 
 // MoEMultiBranchFFN (multi_branch.py:52-61) with SwitchMoELayer top-2 routing (switch_moe.py:44-111)
-int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, const int* forced, float* out) {
+int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, const int* forced, float* out,
+              uint16_t* out16) {
   const MdmModel& m = *c.m;
   const int D = m.D, F = m.F, E = m.E;
   const Work& w = c.w;
@@ -211,11 +258,15 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     p.gate_w[b] = l.gate_w[b], p.gate_b[b] = l.gate_b[b];
     p.usage[b] = l.usage[b], p.importance[b] = l.importance[b];
   }
-  p.hn = w.hn, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.forced_idx = forced;
+  p.hn = w.hn, p.hn_bf16 = c.bf, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.forced_idx = forced;
   MDM_TRY(moe_route(x, c.M, D, E, p, w.goff, w.cursor, w.perm, w.rowscale, w.pos4, c.s));
   {
     GemmArgs g = gemm_defaults(c.prec);  // hidden = GELU(LN_b(x)[routed rows] W1_e^T + b1_e)
-    g.A = op_f32(w.hn, D);
+    if (c.bf) {
+      g.A.p = w.hn, g.A.ld = D, g.A.kind = OP_BF16_ROW;
+    } else {
+      g.A = op_f32(w.hn, D);
+    }
     g.A.gather = w.perm;
     g.W = packed(l.w1);
     g.W.bs1 = (int64_t)F * l.w1.ld;
@@ -223,12 +274,16 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     g.M = (int)(4 * c.M), g.N = F, g.K = D;
     g.bias = l.b1, g.bias_bs = F;
     g.act = ACT_GELU;
-    g.C = w.hid, g.ldc = F;
+    g.C = c.bf ? nullptr : w.hid, g.C16 = c.bf ? (uint16_t*)w.hid : nullptr, g.ldc = F;
     MDM_TRY(gemm(g, c.s));
   }
   {
     GemmArgs g = gemm_defaults(c.prec);  // y2[pos] = prob[pos] * (hidden W2_e^T + b2_e)      (switch_moe.py:108-109)
-    g.A = op_f32(w.hid, F);
+    if (c.bf) {
+      g.A.p = w.hid, g.A.ld = F, g.A.kind = OP_BF16_ROW;
+    } else {
+      g.A = op_f32(w.hid, F);
+    }
     g.W = packed(l.w2);
     g.W.bs1 = (int64_t)D * l.w2.ld;
     g.goff = w.goff, g.ngroups = 2 * E;
@@ -239,15 +294,20 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     MDM_TRY(gemm(g, c.s));
   }
   // mean of the two branches (each the sum of its two routed rows), stylization, residual
-  return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out);
+  return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16);
 }
 
 // MemoryEfficientCrossAttentionBlock (fast_attention.py:301-330); out must not alias x
-int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float* vc, const float* x, float* out) {
+int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float* vc, const float* x, const uint16_t* x16,
+                  float* out, uint16_t* out16) {
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H, N = c.N;
   const Work& w = c.w;
-  MDM_TRY(linear(c, x, c.M, D, l.sd_q, l.sd_q_b, D, w.t1, ACT_NONE, 1.f / sqrtf((float)dh)));
+  {
+    LinOpts o;
+    o.alpha = 1.f / sqrtf((float)dh);
+    MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.sd_q, l.sd_q_b, D, w.t1, nullptr, o));
+  }
   {
     GemmArgs g = gemm_defaults(c.prec);  // scores[b,h,s,n] = q . k
     g.A = op_f32(w.t1, D);
@@ -268,14 +328,20 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
     g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
     g.M = c.S, g.N = dh, g.K = N;
     g.batch = c.B * H, g.nb2 = H;
-    g.C = w.t2, g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
+    g.C = c.bf ? nullptr : w.t2, g.C16 = c.bf ? (uint16_t*)w.t2 : nullptr;
+    g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
     MDM_TRY(gemm(g, c.s));
   }
-  MDM_TRY(linear(c, w.t2, c.M, D, l.sd_out, l.sd_out_b, D, w.t3));
-  MDM_TRY(ln_chain(w.t3, c.M, D, l.sd_ln_w, l.sd_ln_b, w.t4, nullptr, nullptr, nullptr, c.s));
-  MDM_TRY(linear(c, w.t4, c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, w.f1, ACT_GELU));
-  // x + (o + ffn(o))
-  return linear(c, w.f1, c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, ACT_NONE, 1.f, 1.f, x, 1.f, w.t3);
+  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.sd_out, l.sd_out_b, D, w.t3, nullptr));
+  MDM_TRY(ln_chain(w.t3, c.M, D, l.sd_ln_w, l.sd_ln_b, w.t4, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  {
+    LinOpts o;
+    o.act = ACT_GELU;
+    MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, w.f1, o));
+  }
+  LinOpts o;  // x + (o + ffn(o))
+  o.R1 = x, o.R2 = w.t3;
+  return linear(c, act_of(c, w.f1), c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, out16, o);
 }
 
 const float* tc_at(const MdmModel& m, const MdmTextCache& tc, int layer) {
@@ -289,8 +355,8 @@ const float* tc_v(const MdmModel& m, const MdmTextCache& tc, int layer) {
   return tc.sd_v + (int64_t)layer * tc.B * tc.N * m.D;
 }
 
-// one MoEExtendedDecoderLayer (transformer.py:55-64): x (in xin) -> xout; both are workspace or caller buffers
-int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, const float* xin, float* xmid, float* xout,
+// one MoEExtendedDecoderLayer (transformer.py:55-64): x (+ bf16 shadow x16) is updated in place, (y, y16) is scratch
+int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, float* x, uint16_t* x16, float* y, uint16_t* y16,
                   const float* sc4, const int* forced, float* trace) {
   const MdmModel& m = *c.m;
   const MdmLayer& l = m.layers[layer];
@@ -301,14 +367,14 @@ int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, const float* 
                ? MDM_OK
                : MDM_ERR_LAUNCH;
   };
-  MDM_TRY(dual_block(c, l, xin, sc4, xmid));
-  MDM_TRY(dump(0, xmid));
-  MDM_TRY(cross_block(c, l, tc_at(m, tc, layer), xmid, sc4 + 2 * scs, xout));
-  MDM_TRY(dump(1, xout));
-  MDM_TRY(moe_block(c, l, xout, sc4 + 3 * scs, forced, xmid));
-  MDM_TRY(dump(2, xmid));
-  MDM_TRY(sdcross_block(c, l, tc_k(m, tc, layer), tc_v(m, tc, layer), xmid, xout));
-  return dump(3, xout);
+  MDM_TRY(dual_block(c, l, x, x16, sc4, y));
+  MDM_TRY(dump(0, y));
+  MDM_TRY(cross_block(c, l, tc_at(m, tc, layer), y, sc4 + 2 * scs, x));
+  MDM_TRY(dump(1, x));
+  MDM_TRY(moe_block(c, l, x, sc4 + 3 * scs, forced, y, y16));
+  MDM_TRY(dump(2, y));
+  MDM_TRY(sdcross_block(c, l, tc_k(m, tc, layer), tc_v(m, tc, layer), y, y16, x, x16));
+  return dump(3, x);
 }
 
 // fused time/text embedding + every stylization block's (scale|shift)  (transformer.py:313-321, stylization.py:22-27)
@@ -316,26 +382,28 @@ int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj
   const MdmModel& m = *c.m;
   const int D = m.D, Te = 4 * D, B = c.B, nblk = 8 * m.L;
   const Work& w = c.w;
+  LinOpts silu_o;
+  silu_o.act = ACT_SILU;
   MDM_TRY(sinusoid(timesteps, B, D, w.s_a, c.s));
-  MDM_TRY(linear(c, w.s_a, B, D, m.tmlp0, m.tmlp0_b, 2 * D, w.s_b, ACT_SILU));
-  MDM_TRY(linear(c, w.s_b, B, 2 * D, m.tmlp2, m.tmlp2_b, D, w.s_a));
-  MDM_TRY(linear(c, w.s_a, B, D, m.te0, m.te0_b, Te, w.s_b, ACT_SILU));
-  MDM_TRY(linear(c, w.s_b, B, Te, m.te2, m.te2_b, Te, w.s_c));
-  MDM_TRY(linear(c, w.s_c, B, Te, m.tproj, m.tproj_b, D, w.s_a));
-  MDM_TRY(linear(c, w.s_a, B, D, m.gf_time, m.gf_time_b, D, w.s_b));  // t
+  MDM_TRY(linear(c, act_f32(w.s_a), B, D, m.tmlp0, m.tmlp0_b, 2 * D, w.s_b, nullptr, silu_o));
+  MDM_TRY(linear(c, act_f32(w.s_b), B, 2 * D, m.tmlp2, m.tmlp2_b, D, w.s_a, nullptr));
+  MDM_TRY(linear(c, act_f32(w.s_a), B, D, m.te0, m.te0_b, Te, w.s_b, nullptr, silu_o));
+  MDM_TRY(linear(c, act_f32(w.s_b), B, Te, m.te2, m.te2_b, Te, w.s_c, nullptr));
+  MDM_TRY(linear(c, act_f32(w.s_c), B, Te, m.tproj, m.tproj_b, D, w.s_a, nullptr));
+  MDM_TRY(linear(c, act_f32(w.s_a), B, D, m.gf_time, m.gf_time_b, D, w.s_b, nullptr));  // t
   const float* tp = xf_proj;
   if (m.Dt != D) {  // the per-call random text_proj (transformer.py:313-315), captured
     if (!m.text_proj.hi) return MDM_ERR_ARG;
-    MDM_TRY(linear(c, xf_proj, B, m.Dt, m.text_proj, m.text_proj_b, D, w.s_c));
+    MDM_TRY(linear(c, act_f32(xf_proj), B, m.Dt, m.text_proj, m.text_proj_b, D, w.s_c, nullptr));
     tp = w.s_c;
   }
-  MDM_TRY(linear(c, tp, B, D, m.gf_text, m.gf_text_b, D, w.s_a));  // x
+  MDM_TRY(linear(c, act_f32(tp), B, D, m.gf_text, m.gf_text_b, D, w.s_a, nullptr));  // x
   MDM_TRY(gated_mix(w.s_b, w.s_a, (int64_t)B * D, w.s_c, c.s));
-  MDM_TRY(linear(c, w.s_c, B, D, m.gf_post0, m.gf_post0_b, D, w.s_a, ACT_SILU));
+  MDM_TRY(linear(c, act_f32(w.s_c), B, D, m.gf_post0, m.gf_post0_b, D, w.s_a, nullptr, silu_o));
   float* emb = emb_out ? emb_out : w.emb;
-  MDM_TRY(linear(c, w.s_a, B, D, m.gf_post2, m.gf_post2_b, D, emb));
+  MDM_TRY(linear(c, act_f32(w.s_a), B, D, m.gf_post2, m.gf_post2_b, D, emb, nullptr));
   // all 8L blocks at once: e1 = SiLU(emb Weph^T + beph) [B, 8L*Te]; sc[j] = e1[:, j] W1_j^T + b1_j [8L, B, 2D]
-  MDM_TRY(linear(c, emb, B, D, m.style_eph, m.style_eph_b, nblk * Te, w.e1, ACT_SILU));
+  MDM_TRY(linear(c, act_f32(emb), B, D, m.style_eph, m.style_eph_b, nblk * Te, w.e1, nullptr, silu_o));
   GemmArgs g = gemm_defaults(c.prec);
   g.A = op_f32(w.e1, (int64_t)nblk * Te);
   g.A.bs1 = Te;
@@ -347,6 +415,9 @@ int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj
   g.C = sc_out, g.ldc = 2 * D, g.c_bs1 = (int64_t)B * 2 * D;
   return gemm(g, c.s);
 }
+
+// bf16 activation plumbing needs every GEMM K (D, 2D, 4D, F) to be a multiple of the 64-wide LDS-DMA k-tile
+bool use_bf16_acts(const MdmModel* m, int precision) { return precision == 1 && m->D % 64 == 0 && m->F % 64 == 0; }
 
 int check_model(const MdmModel* m) {
   if (!m || !m->layers || m->D <= 0 || m->H <= 0 || m->D % m->H || m->L <= 0 || m->E < 2 || m->E > 16) return MDM_ERR_ARG;
@@ -374,17 +445,17 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
   if (!xf_out || !tc || !tc->lin_at || !tc->sd_k || !tc->sd_v || tc->B <= 0 || tc->N <= 0 || tc->N > 128 || !ws)
     return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.B = tc->B, c.N = tc->N;
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = tc->B, c.N = tc->N;
   c.w = carve(*m, tc->B, 2, tc->N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const int D = m->D, H = m->H, dh = D / H, N = tc->N, B = tc->B;
   const int64_t BN = (int64_t)B * N;
   for (int layer = 0; layer < 2 * m->L; ++layer) {
     const MdmLayer& l = m->layers[layer];
-    MDM_TRY(ln_chain(xf_out, BN, m->Dt, l.ca_tnorm_w, l.ca_tnorm_b, c.w.tn, nullptr, nullptr, nullptr, c.s));
-    MDM_TRY(linear(c, c.w.tn, BN, m->Dt, l.ca_k, l.ca_k_b, D, c.w.kb));
+    MDM_TRY(ln_chain(xf_out, BN, m->Dt, l.ca_tnorm_w, l.ca_tnorm_b, c.w.tn, 0, nullptr, nullptr, nullptr, 0, c.s));
+    MDM_TRY(linear(c, act_f32(c.w.tn), BN, m->Dt, l.ca_k, l.ca_k_b, D, c.w.kb, nullptr));
     MDM_TRY(col_softmax(c.w.kb, B, N, D, c.s));  // softmax over text tokens (fast_attention.py:249)
-    MDM_TRY(linear(c, c.w.tn, BN, m->Dt, l.ca_v, l.ca_v_b, D, c.w.vb));
+    MDM_TRY(linear(c, act_f32(c.w.tn), BN, m->Dt, l.ca_v, l.ca_v_b, D, c.w.vb, nullptr));
     GemmArgs g = gemm_defaults(precision);  // A^T[b,h][l][d] = sum_n v[n,l] k[n,d]   (fast_attention.py:252)
     g.A = op_f32_kstride(c.w.vb, D);
     g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
@@ -394,8 +465,8 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
     g.batch = B * H, g.nb2 = H;
     g.C = (float*)tc_at(*m, *tc, layer), g.ldc = dh, g.c_bs1 = (int64_t)H * dh * dh, g.c_bs2 = (int64_t)dh * dh;
     MDM_TRY(gemm(g, c.s));
-    MDM_TRY(linear(c, xf_out, BN, m->Dt, l.sd_k, l.sd_k_b, D, (float*)tc_k(*m, *tc, layer)));
-    MDM_TRY(linear(c, xf_out, BN, m->Dt, l.sd_v, l.sd_v_b, D, (float*)tc_v(*m, *tc, layer)));
+    MDM_TRY(linear(c, act_f32(xf_out), BN, m->Dt, l.sd_k, l.sd_k_b, D, (float*)tc_k(*m, *tc, layer), nullptr));
+    MDM_TRY(linear(c, act_f32(xf_out), BN, m->Dt, l.sd_v, l.sd_v_b, D, (float*)tc_v(*m, *tc, layer), nullptr));
   }
   return MDM_OK;
 }
@@ -405,7 +476,7 @@ int mdm_stem_embeddings(const MdmModel* m, const int64_t* timesteps, const float
   MDM_TRY(check_model(m));
   if (!timesteps || !xf_proj || !sc_out || !ws || B <= 0) return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.B = B;
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B;
   c.w = carve(*m, B, 2, 1, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   return stem_embeddings(c, timesteps, xf_proj, emb_out, sc_out);
@@ -419,7 +490,7 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
   if (T % 2 || T > m->num_frames) return MDM_ERR_ARG;  // odd T breaks the U-shape (transformer.py:223-224,353)
   if (tc->B != B) return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.B = B, c.N = tc->N;
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B, c.N = tc->N;
   c.w = carve(*m, B, T, tc->N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const Work& w = c.w;
@@ -428,26 +499,35 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
   const int64_t scl = (int64_t)4 * B * 2 * D;  // (scale|shift) floats per layer
   MDM_TRY(stem_embeddings(c, timesteps, xf_proj, nullptr, w.sc));
   // h = joint_embed(x) + sequence_embedding[:T]                     (transformer.py:324-326)
-  MDM_TRY(linear(c, x, Mfull, m->feats, m->joint, m->joint_b, D, w.h0, ACT_NONE, 1.f, 1.f, m->seq_emb, 1.f, nullptr,
-                 nullptr, T));
+  {
+    LinOpts o;
+    o.R1 = m->seq_emb, o.r1_mod = T;
+    MDM_TRY(linear(c, act_f32(x), Mfull, m->feats, m->joint, m->joint_b, D, w.h0, c.bf ? w.h016 : nullptr, o));
+  }
   // Conv1d(k=2,s=2) == Linear over pairs of frames                  (:332-337)
-  MDM_TRY(linear(c, w.h0, Mlow, 2 * D, m->down, m->down_b, D, w.xa));
+  MDM_TRY(linear(c, c.bf ? act_bf16(w.h016) : act_f32(w.h0), Mlow, 2 * D, m->down, m->down_b, D, w.xa,
+                 c.bf ? w.xa16 : nullptr));
   MDM_TRY(halve_lengths(length, B, w.len_low, c.s));  // (:341-342)
   c.S = T / 2, c.M = Mlow, c.len = w.len_low;
-  for (int i = 0; i < L; ++i) {  // coarse scale blocks: xa -> xa (xb = intermediate)   (:343-344)
+  for (int i = 0; i < L; ++i) {  // coarse scale blocks, in place on xa (xb = scratch)      (:343-344)
     const int32_t* fr = forced_routing ? forced_routing + (int64_t)i * 4 * Mfull : nullptr;
     float* tr = trace ? trace + (int64_t)i * 4 * Mfull * D : nullptr;
-    MDM_TRY(decoder_layer(c, i, *tc, w.xa, w.xb, w.xa, w.sc + i * scl, fr, tr));
+    MDM_TRY(decoder_layer(c, i, *tc, w.xa, w.xa16, w.xb, w.xb16, w.sc + i * scl, fr, tr));
   }
   // ConvTranspose1d(k=2,s=2) == Linear D -> 2D per coarse frame, rows (B*T/2, 2D) == (B*T, D); + skip h  (:347-353)
-  MDM_TRY(linear(c, w.xa, Mlow, D, m->up, m->up_b2, 2 * D, w.xb, ACT_NONE, 1.f, 1.f, w.h0));
+  {
+    LinOpts o;
+    o.R1 = w.h0;
+    MDM_TRY(linear(c, c.bf ? act_bf16(w.xa16) : act_f32(w.xa), Mlow, D, m->up, m->up_b2, 2 * D, w.xb,
+                   c.bf ? w.xb16 : nullptr, o));
+  }
   c.S = T, c.M = Mfull, c.len = length;
-  for (int i = 0; i < L; ++i) {  // full scale blocks: xb -> xb                           (:356-357)
+  for (int i = 0; i < L; ++i) {  // full scale blocks, in place on xb                        (:356-357)
     const int32_t* fr = forced_routing ? forced_routing + (int64_t)(L + i) * 4 * Mfull : nullptr;
     float* tr = trace ? trace + (int64_t)(L + i) * 4 * Mfull * D : nullptr;
-    MDM_TRY(decoder_layer(c, L + i, *tc, w.xb, w.xa, w.xb, w.sc + (L + i) * scl, fr, tr));
+    MDM_TRY(decoder_layer(c, L + i, *tc, w.xb, w.xb16, w.xa, w.xa16, w.sc + (L + i) * scl, fr, tr));
   }
-  return linear(c, w.xb, Mfull, D, m->out, m->out_b, m->feats, out);  // (:360)
+  return linear(c, c.bf ? act_bf16(w.xb16) : act_f32(w.xb), Mfull, D, m->out, m->out_b, m->feats, out, nullptr);  // (:360)
 }
 
 int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const MdmTextCache* tc, const float* h,
@@ -458,21 +538,24 @@ int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const Mdm
   if ((block == MDM_BLOCK_CROSS || block == MDM_BLOCK_SDCROSS || block == MDM_BLOCK_LAYER) && (!tc || tc->B != B))
     return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.B = B, c.S = S, c.M = (int64_t)B * S, c.len = len;
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B, c.S = S, c.M = (int64_t)B * S, c.len = len;
   c.N = tc ? tc->N : 1;
   c.w = carve(*m, B, S, c.N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const MdmLayer& l = m->layers[layer];
-  const int64_t scs = (int64_t)B * 2 * m->D;
+  const int64_t scs = (int64_t)B * 2 * m->D, n = c.M * m->D;
+  if (c.bf && (n & 3)) return MDM_ERR_UNSUPPORTED;
+  if (c.bf) MDM_TRY(to_bf16(h, n, c.w.h016, c.s));  // callers hand over fp32 only: build the bf16 shadow here
   switch (block) {
-    case MDM_BLOCK_DUAL: return dual_block(c, l, h, sc, out);
+    case MDM_BLOCK_DUAL: return dual_block(c, l, h, c.w.h016, sc, out);
     case MDM_BLOCK_CROSS: return cross_block(c, l, tc_at(*m, *tc, layer), h, sc + 2 * scs, out);
-    case MDM_BLOCK_MOE: return moe_block(c, l, h, sc + 3 * scs, forced_routing, out);
-    case MDM_BLOCK_SDCROSS: return sdcross_block(c, l, tc_k(*m, *tc, layer), tc_v(*m, *tc, layer), h, out);
+    case MDM_BLOCK_MOE: return moe_block(c, l, h, sc + 3 * scs, forced_routing, out, nullptr);
+    case MDM_BLOCK_SDCROSS:
+      return sdcross_block(c, l, tc_k(*m, *tc, layer), tc_v(*m, *tc, layer), h, c.w.h016, out, nullptr);
     case MDM_BLOCK_LAYER: {
-      const int64_t n = c.M * m->D;
       if (hipMemcpyAsync(c.w.xa, h, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) != hipSuccess) return MDM_ERR_LAUNCH;
-      MDM_TRY(decoder_layer(c, layer, *tc, c.w.xa, c.w.xb, c.w.xa, sc, forced_routing, nullptr));
+      if (c.bf) MDM_TRY(to_bf16(h, n, c.w.xa16, c.s));
+      MDM_TRY(decoder_layer(c, layer, *tc, c.w.xa, c.w.xa16, c.w.xb, c.w.xb16, sc, forced_routing, nullptr));
       return hipMemcpyAsync(out, c.w.xa, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) == hipSuccess ? MDM_OK
                                                                                                          : MDM_ERR_LAUNCH;
     }
@@ -486,7 +569,7 @@ int mdm_stylization_forward(const MdmStyle* st, const float* h, const float* sc,
   MdmModel fake = {};
   fake.D = D;
   Ctx c = {};
-  c.m = &fake, c.s = (hipStream_t)stream, c.prec = precision, c.B = B, c.S = S, c.M = (int64_t)B * S;
+  c.m = &fake, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B, c.S = S, c.M = (int64_t)B * S;
   return style_apply(c, *st, h, nullptr, nullptr, nullptr, sc, tmp, nullptr, 1.f, nullptr, out);
 }
 

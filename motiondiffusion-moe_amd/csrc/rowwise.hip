@@ -43,6 +43,27 @@ struct Row {
       }
     }
   }
+  // bf16 (round-to-nearest-even) copy of the row, for tensors whose only consumer is a bf16 MFMA GEMM
+  __device__ __forceinline__ void store_bf16(uint16_t* __restrict__ p, int D, int lane) const {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c)
+        *(uint2*)(p + 4 * (lane + 64 * c)) = make_uint2(pack_bf16(e[4 * c + 0], e[4 * c + 1]), pack_bf16(e[4 * c + 2], e[4 * c + 3]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int i = lane + 64 * j;
+        if (i < D) p[i] = (uint16_t)(pack_bf16(e[j], 0.f) & 0xffff);
+      }
+    }
+  }
+  __device__ __forceinline__ void store_as(void* __restrict__ p, int64_t row, int D, int lane, int bf16) const {
+    if (bf16) {
+      store_bf16((uint16_t*)p + row * D, D, lane);
+    } else {
+      store((float*)p + row * D, D, lane);
+    }
+  }
   __device__ __forceinline__ float sum() const {
     float s = 0.f;
 #pragma unroll
@@ -91,17 +112,17 @@ struct Row {
 // ---- LN chain: y1 = LN1(x), y2 = LN2(y1) --------------------------------------------------------
 template <int NE, bool VEC>
 __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, int64_t M, int D,
-                                                       const float* w1, const float* b1, float* y1,
-                                                       const float* w2, const float* b2, float* y2) {
+                                                       const float* w1, const float* b1, void* y1, int y1_bf,
+                                                       const float* w2, const float* b2, void* y2, int y2_bf) {
   const int lane = threadIdx.x & 63;
   for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
     Row<NE, VEC> r;
     r.load(x + row * D, D, lane);
     r.layernorm(w1, b1, D, lane);
-    if (y1) r.store(y1 + row * D, D, lane);
+    if (y1) r.store_as(y1, row, D, lane, y1_bf);
     if (w2) {
       r.layernorm(w2, b2, D, lane);
-      r.store(y2 + row * D, D, lane);
+      r.store_as(y2, row, D, lane, y2_bf);
     }
   }
 }
@@ -116,7 +137,7 @@ __global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__
                                                        const float* sw, const float* sb,  // style norm
                                                        const float* __restrict__ sc,      // (B, 2D) scale|shift
                                                        const int* __restrict__ pos4,      // optional (M,4) rows of y2
-                                                       float* __restrict__ out) {
+                                                       void* __restrict__ out, int out_bf) {
   const int lane = threadIdx.x & 63;
   for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
     Row<NE, VEC> r;
@@ -147,7 +168,7 @@ __global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__
     shift.load(scb + D, D, lane);
 #pragma unroll
     for (int j = 0; j < NE; ++j) r.e[j] = silu(r.e[j] * (1.f + scale.e[j]) + shift.e[j]);
-    r.store(out + row * D, D, lane);
+    r.store_as(out, row, D, lane, out_bf);
   }
 }
 
@@ -155,6 +176,12 @@ __global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__
 template <int NE, bool VEC>
 __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__ x, int64_t M, int D, int E,
                                                        MoeGateParams p) {
+  // per-block counters in LDS, flushed with ONE global atomic per (branch, expert) per block: thousands of
+  // tokens adding straight into 2E global words serialise at the memory side
+  __shared__ int s_hist[32];
+  __shared__ float s_usage[32], s_imp[32];
+  if (threadIdx.x < 32) s_hist[threadIdx.x] = 0, s_usage[threadIdx.x] = 0.f, s_imp[threadIdx.x] = 0.f;
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
     Row<NE, VEC> xr;
@@ -163,7 +190,7 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
     for (int br = 0; br < 2; ++br) {
       Row<NE, VEC> r = xr;
       r.layernorm(p.ln_w[br], p.ln_b[br], D, lane);
-      r.store(p.hn + ((int64_t)br * M + row) * D, D, lane);
+      r.store_as(p.hn, (int64_t)br * M + row, D, lane, p.hn_bf16);
       float logit[16];
       float mx = -INFINITY;
 #pragma unroll
@@ -215,14 +242,21 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
         const int64_t o = ((int64_t)br * M + row) * 2;
         p.top_idx[o] = i1, p.top_idx[o + 1] = i2;
         p.top_val[o] = v1, p.top_val[o + 1] = v2;
-        atomicAdd(&p.hist[br * E + i1], 1);
-        atomicAdd(&p.hist[br * E + i2], 1);
-        if (p.usage[br]) {  // switch_moe.py:71-92 counters, device side, no host sync
-          atomicAdd(&p.usage[br][i1], 1.f);
-          atomicAdd(&p.importance[br][i1], v1);
-          atomicAdd(&p.importance[br][i2], v2);
-        }
+        atomicAdd(&s_hist[br * E + i1], 1);
+        atomicAdd(&s_hist[br * E + i2], 1);
+        atomicAdd(&s_usage[br * E + i1], 1.f);  // switch_moe.py:71-92 counters, device side, no host sync
+        atomicAdd(&s_imp[br * E + i1], v1);
+        atomicAdd(&s_imp[br * E + i2], v2);
       }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * E) {
+    const int g = threadIdx.x, br = g / E, e = g - br * E;
+    if (s_hist[g]) atomicAdd(&p.hist[g], s_hist[g]);
+    if (p.usage[br] && s_imp[g] != 0.f) {
+      if (s_usage[g] != 0.f) atomicAdd(&p.usage[br][e], s_usage[g]);
+      atomicAdd(&p.importance[br][e], s_imp[g]);
     }
   }
 }
@@ -239,18 +273,38 @@ __global__ void moe_offsets_kernel(const int* __restrict__ hist, int G, int* __r
   }
 }
 
-__global__ void moe_assign_kernel(const int* __restrict__ top_idx, const float* __restrict__ top_val, int64_t M, int E,
-                                  const int* __restrict__ goff, int* __restrict__ cursor, int* __restrict__ perm,
-                                  float* __restrict__ rowscale, int* __restrict__ pos4) {
+// positions inside each expert's contiguous slab: rank within the block from an LDS counter, one global
+// atomic per (block, expert) to reserve the block's range.  Order within a slab is irrelevant (rows are independent).
+__global__ __launch_bounds__(256) void moe_assign_kernel(const int* __restrict__ top_idx, const float* __restrict__ top_val,
+                                                         int64_t M, int E, const int* __restrict__ goff,
+                                                         int* __restrict__ cursor, int* __restrict__ perm,
+                                                         float* __restrict__ rowscale, int* __restrict__ pos4) {
+  __shared__ int s_cnt[32], s_base[32];
   const int64_t total = 2 * M * 2;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t br = i / (2 * M), rem = i - br * 2 * M, tok = rem >> 1;
-    const int k = (int)(rem & 1);
-    const int g = (int)br * E + top_idx[i];
-    const int pos = goff[g] + atomicAdd(&cursor[g], 1);
-    perm[pos] = (int)(br * M + tok);
-    rowscale[pos] = top_val[i];
-    pos4[tok * 4 + br * 2 + k] = pos;
+  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+    if (threadIdx.x < 32) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = base + threadIdx.x;
+    int g = -1, rank = 0;
+    int64_t br = 0, tok = 0;
+    int k = 0;
+    if (i < total) {
+      br = i / (2 * M);
+      const int64_t rem = i - br * 2 * M;
+      tok = rem >> 1, k = (int)(rem & 1);
+      g = (int)br * E + top_idx[i];
+      rank = atomicAdd(&s_cnt[g], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * E && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (g >= 0) {
+      const int pos = goff[g] + s_base[g] + rank;
+      perm[pos] = (int)(br * M + tok);
+      rowscale[pos] = top_val[i];
+      pos4[tok * 4 + br * 2 + k] = pos;
+    }
+    __syncthreads();
   }
 }
 
@@ -290,7 +344,7 @@ __global__ __launch_bounds__(256) void head_norm_kernel(float* __restrict__ qkv,
 template <int G>
 __global__ __launch_bounds__(256) void den_ln_kernel(const float* __restrict__ num, const float* __restrict__ phi,
                                                      int64_t M, int H, int dh, const float* w, const float* b,
-                                                     float* __restrict__ out) {
+                                                     void* __restrict__ out, int out_bf) {
   const int gl = threadIdx.x % G;
   const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
   const int64_t ng = (int64_t)gridDim.x * blockDim.x / G;
@@ -303,7 +357,11 @@ __global__ __launch_bounds__(256) void den_ln_kernel(const float* __restrict__ n
     f32x4 v = *(const f32x4*)(num + u * dh + 4 * gl);
     v = (f32x4){v[0] / den, v[1] / den, v[2] / den, v[3] / den};
     head_ln<G>(v, w, b, dh, gl);
-    *(f32x4*)(out + u * dh + 4 * gl) = v;
+    if (out_bf) {
+      *(uint2*)((uint16_t*)out + u * dh + 4 * gl) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    } else {
+      *(f32x4*)((float*)out + u * dh + 4 * gl) = v;
+    }
   }
 }
 
@@ -462,6 +520,13 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
+__global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n4, uint16_t* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 v = *(const f32x4*)(src + 4 * i);
+    *(uint2*)(dst + 4 * i) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+  }
+}
+
 __global__ void fill_i64_kernel(int64_t* dst, int64_t n, const int* src) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (int64_t)*src;
@@ -480,12 +545,12 @@ inline int unit_grid(int64_t units, int G) {
 
 }  // namespace
 
-int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, float* y1, const float* w2,
-             const float* b2, float* y2, hipStream_t s) {
+int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, void* y1, int y1_bf, const float* w2,
+             const float* b2, void* y2, int y2_bf, hipStream_t s) {
   if (M <= 0) return MDM_OK;
   if (!x || !w1 || !b1 || (w2 && (!b2 || !y2)) || (!w2 && !y1)) return MDM_ERR_ARG;
 #define CALL(NE, VEC) \
-  hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, w1, b1, y1, w2, b2, y2)
+  hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, w1, b1, y1, y1_bf, w2, b2, y2, y2_bf)
   MDM_ROW_DISPATCH(D, CALL);
 #undef CALL
   MDM_RETURN_IF_LAUNCH_FAILED();
@@ -493,12 +558,12 @@ int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1,
 }
 
 int style_in(const float* x, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw,
-             const float* sb, const float* sc, const int* pos4, float* out, hipStream_t s) {
+             const float* sb, const float* sc, const int* pos4, void* out, int out_bf, hipStream_t s) {
   if (M <= 0) return MDM_OK;
   if (!x || !sw || !sb || !sc || !out || S <= 0) return MDM_ERR_ARG;
 #define CALL(NE, VEC)                                                                                              \
   hipLaunchKernelGGL((style_in_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, S, pw, pb, sw, sb, sc, \
-                     pos4, out)
+                     pos4, out, out_bf)
   MDM_ROW_DISPATCH(D, CALL);
 #undef CALL
   MDM_RETURN_IF_LAUNCH_FAILED();
@@ -510,13 +575,14 @@ int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, i
   if (M <= 0) return MDM_OK;
   if (E < 2 || E > 16 || !x || !p.hn || !p.hist || !p.top_idx || !p.top_val) return MDM_ERR_ARG;
   if (hipMemsetAsync(p.hist, 0, sizeof(int) * 2 * E, s) != hipSuccess) return MDM_ERR_LAUNCH;
-#define CALL(NE, VEC) hipLaunchKernelGGL((moe_gate_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, E, p)
+  const int gate_grid = row_grid(M) > 1024 ? 1024 : row_grid(M);
+#define CALL(NE, VEC) hipLaunchKernelGGL((moe_gate_kernel<NE, VEC>), dim3(gate_grid), dim3(256), 0, s, x, M, D, E, p)
   MDM_ROW_DISPATCH(D, CALL);
 #undef CALL
   hipLaunchKernelGGL(moe_offsets_kernel, dim3(1), dim3(64), 0, s, p.hist, 2 * E, goff, cursor);
   const int64_t total = 4 * M;
   int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(moe_assign_kernel, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s, p.top_idx, p.top_val, M, E,
+  hipLaunchKernelGGL(moe_assign_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, p.top_idx, p.top_val, M, E,
                      goff, cursor, perm, rowscale, pos4);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
@@ -532,11 +598,11 @@ int head_norm(float* qkv, int64_t M, int H, int dh, const float* w, const float*
   return MDM_OK;
 }
 
-int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const float* w, const float* b, float* out,
-           hipStream_t s) {
+int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const float* w, const float* b, void* out,
+           int out_bf, hipStream_t s) {
   if (M <= 0) return MDM_OK;
 #define CALL(G) \
-  hipLaunchKernelGGL((den_ln_kernel<G>), dim3(unit_grid(M * H, G)), dim3(256), 0, s, num, phi, M, H, dh, w, b, out)
+  hipLaunchKernelGGL((den_ln_kernel<G>), dim3(unit_grid(M * H, G)), dim3(256), 0, s, num, phi, M, H, dh, w, b, out, out_bf)
   MDM_HEAD_DISPATCH(dh, CALL);
 #undef CALL
   MDM_RETURN_IF_LAUNCH_FAILED();
@@ -588,6 +654,15 @@ int xattn_gate(const float* gate, const float* ag, int D, float* out, hipStream_
 
 int halve_lengths(const int* len, int B, int* out, hipStream_t s) {
   hipLaunchKernelGGL(halve_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, s, len, B, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int to_bf16(const float* src, int64_t n, uint16_t* dst, hipStream_t s) {
+  if (n <= 0) return MDM_OK;
+  if (n & 3) return MDM_ERR_ARG;
+  int64_t blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, src, n / 4, dst);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

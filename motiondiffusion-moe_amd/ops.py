@@ -60,8 +60,10 @@ def run_gemm(d: L.GemmDesc):
 
 def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
            alpha: float = 1.0, out_scale: float = 1.0, colscale=None, rowscale=None, r1=None, r1_scale: float = 1.0,
-           r1_mod: int = 0, r2=None, precision: int = 3, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = epilogue(x @ w^T): the fused Linear used throughout the denoiser."""
+           r1_mod: int = 0, r2=None, precision: int = 3, out: Optional[torch.Tensor] = None,
+           out16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epilogue(x @ w^T): the fused Linear used throughout the denoiser.  bf16 ``x`` selects the throughput
+    kernel (gemm2.hip); ``out16`` receives an optional bf16 copy of the result."""
     L.require_cuda(x)
     K = x.shape[-1]
     assert K == w.K, (K, w.K)
@@ -71,10 +73,16 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty((M, w.N), dtype=torch.float32, device=x.device)
     d = gemm_desc(precision)
-    d.A = f32_operand(x2, x2.stride(0))
+    if x2.dtype == torch.bfloat16:
+        d.A.p, d.A.ld, d.A.kind = x2.data_ptr(), x2.stride(0), L.OP_BF16_ROW
+    else:
+        d.A = f32_operand(x2, x2.stride(0))
     d.W = w.operand()
     d.M, d.N, d.K = M, w.N, K
     d.C, d.ldc = out.data_ptr(), out.stride(0)
+    if out16 is not None:
+        assert out16.stride(0) == out.stride(0)
+        d.C16 = out16.data_ptr()
     d.bias = L.ptr(bias)
     d.act, d.alpha, d.out_scale = act, alpha, out_scale
     d.colscale, d.rowscale = L.ptr(colscale), L.ptr(rowscale)

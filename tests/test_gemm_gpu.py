@@ -169,3 +169,54 @@ def test_gemm_rejects_bad_args():
     assert L.lib().mdm_gemm(C.byref(d), C.c_void_p(0)) == 0  # empty problem is a no-op
     d.M = d.N = d.K = 32
     assert L.lib().mdm_gemm(C.byref(d), C.c_void_p(0)) == 1  # null operands
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (12544, 512, 512), (200, 263, 512), (70, 512, 1024), (1, 96, 64),
+                                   (392, 1536, 512)])
+def test_bf16_activation_kernel(M, N, K):
+    """gemm2.hip: bf16 A via LDS-DMA, swapped-operand epilogue; result must equal the fp32-A kernel fed the same
+    bf16-rounded inputs (both accumulate bf16 products in fp32)."""
+    L, ops = _mods()
+    x, w, b = _rand(M, K, seed=21), _rand(N, K, seed=22), _rand(N, seed=23)
+    xb = x.to(torch.bfloat16)
+    pw = ops.PackedWeight(w)
+    r1, r2, cs, rs = _rand(M, N, seed=24), _rand(M, N, seed=25), _rand(N, seed=26), _rand(M, seed=27)
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    y = ops.linear(xb, pw, b, act=L.ACT_GELU, alpha=0.9, out_scale=0.5, colscale=cs, rowscale=rs, r1=r1, r1_scale=0.3,
+                   r2=r2, precision=1, out16=out16)
+    ref = torch.nn.functional.gelu(0.9 * (xb.double() @ w.to(torch.bfloat16).double().T + b.double())) * 0.5
+    ref = ref * cs.double()[None] * rs.double()[:, None] + 0.3 * r1.double() + r2.double()
+    assert rel_inf(y.cpu(), ref.float().cpu()) < 1e-4
+    assert rel_inf(out16.float().cpu(), ref.float().cpu()) < 1e-2
+    assert torch.equal(out16, y.to(torch.bfloat16))
+
+
+def test_bf16_kernel_grouped_gather():
+    L, ops = _mods()
+    E, D, F_, Mtok = 5, 128, 192, 333
+    x = _rand(Mtok, D, seed=31).to(torch.bfloat16)
+    w, b = _rand(E, F_, D, seed=32), _rand(E, F_, seed=33)
+    counts = torch.tensor([0, 130, 1, 257, 61])
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = counts.cumsum(0)
+    tot = int(off[-1])
+    gather = torch.randint(0, Mtok, (tot,), generator=torch.Generator().manual_seed(3), dtype=torch.int32)
+    pw = ops.PackedWeight(w)
+    out = torch.zeros(tot, F_, device="cuda")
+    d = ops.gemm_desc(1)
+    gd, od = gather.cuda(), off.cuda()
+    d.A.p, d.A.ld, d.A.kind, d.A.gather = x.data_ptr(), D, L.OP_BF16_ROW, gd.data_ptr()
+    d.W = pw.operand()
+    d.W.bs1 = F_ * pw.Kp
+    d.goff, d.ngroups = od.data_ptr(), E
+    d.M, d.N, d.K = tot, F_, D
+    d.bias, d.bias_bs = b.data_ptr(), F_
+    d.C, d.ldc = out.data_ptr(), F_
+    d.act = L.ACT_GELU
+    ops.run_gemm(d)
+    ref = torch.empty(tot, F_, dtype=torch.float64)
+    wb = w.to(torch.bfloat16).cpu().double()
+    for e in range(E):
+        r = slice(int(off[e]), int(off[e + 1]))
+        ref[r] = torch.nn.functional.gelu(x.cpu().double()[gather[r].long()] @ wb[e].T + b[e].cpu().double())
+    assert rel_inf(out.cpu(), ref.float()) < 1e-4
