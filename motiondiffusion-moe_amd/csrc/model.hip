@@ -569,7 +569,8 @@ int mdm_stylization_forward(const MdmStyle* st, const float* h, const float* sc,
   MdmModel fake = {};
   fake.D = D;
   Ctx c = {};
-  c.m = &fake, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B, c.S = S, c.M = (int64_t)B * S;
+  c.m = &fake, c.s = (hipStream_t)stream, c.prec = precision, c.bf = (precision == 1 && D % 64 == 0), c.B = B, c.S = S,
+  c.M = (int64_t)B * S;
   return style_apply(c, *st, h, nullptr, nullptr, nullptr, sc, tmp, nullptr, 1.f, nullptr, out);
 }
 
