@@ -106,6 +106,66 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     for (int i = 0; i < PPW; ++i) glds16(pw[i] + k0, sw + i * 1024);
   };
 
+  // Everything the epilogue reads (bias / column scales / row scales / residuals) is fetched BEFORE the K loop and
+  // rides in registers: at K = 512 the loop is only 8 tiles long and an epilogue that starts with a dependent
+  // global round trip per row was a third of the block's latency.  Outputs never alias these inputs.
+  float* __restrict__ C = g.C ? g.C + offC : nullptr;
+  uint16_t* __restrict__ C16 = g.C16 ? g.C16 + offC : nullptr;
+  const float* __restrict__ bias = g.bias ? g.bias + offB : nullptr;
+  const float* __restrict__ colscale = g.colscale;
+  const float* __restrict__ R1 = g.R1;
+  const float* __restrict__ R2 = g.R2;
+  const bool vec = ((g.ldc & 3) == 0) && (!R1 || (g.ldr1 & 3) == 0) && (!R2 || (g.ldr2 & 3) == 0);
+  const int fq = lane >> 4;
+  const int nbase = nt * BN + wn * 64 + fq * 4;
+  float bv[4][4], cv[4][4], rs[4];
+  f32x4 q1a[2][4], q1b[2][4];  // first residual: rows i = 0,1 prefetched here, rows 2,3 at the top of the epilogue
+  bool keymask[4];
+  int64_t mrow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nbase + j * 16 + r;
+      const int nn = n < g.N ? n : g.N - 1;
+      bv[j][r] = bias ? bias[nn] : 0.f;
+      cv[j][r] = g.out_scale * (colscale ? colscale[nn] : 1.f);
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+    const bool ok = m < row_end;
+    rs[i] = (ok && g.rowscale) ? g.rowscale[m] : 1.f;
+    const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
+    keymask[i] = false;
+    if (ok && ACT == ACT_FEAT && g.feat_len) {
+      const int tok = m / g.feat_rpt, slot = m - tok * g.feat_rpt;
+      if (slot >= g.feat_kslot) {
+        const int bb = tok / g.feat_S, t = tok - bb * g.feat_S;
+        keymask[i] = t >= g.feat_len[bb];
+      }
+    }
+    mrow[i] = mr;
+  }
+  auto fetch_r1 = [&](int i, f32x4 (&dst)[4]) {
+    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nbase + j * 16;
+      dst[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!R1 || m >= row_end) continue;
+      if (vec && n + 3 < g.N) {
+        dst[j] = *(const f32x4*)(R1 + mrow[i] * g.ldr1 + n);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < g.N) dst[j][r] = R1[mrow[i] * g.ldr1 + n + r];
+      }
+    }
+  };
+  fetch_r1(0, q1a[0]);
+  fetch_r1(1, q1a[1]);
+
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -118,7 +178,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     if (s < nk) stage(s, s);
 
   constexpr int PIECES = 2 * PPW;  // LDS-DMA instructions per wave per K-tile
-  const int frow = lane & 15, fq = lane >> 4;
+  const int frow = lane & 15;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once each wave's pieces for it have: wait for all but the younger tiles, then barrier
     const int younger = min(NSTAGE - 2, nk - 1 - kt);
@@ -150,56 +210,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     }
   }
 
-  // epilogue.  D tile (j,i): lane holds n = nb + 4*(lane>>4) + r (r = 0..3) for m = mb + (lane & 15).
-  // All loads of a row are issued before its stores and the pointers are restrict-qualified: the outputs never
-  // alias bias / residual inputs, and a load that has to wait behind each store serialises the whole tile.
-  float* __restrict__ C = g.C ? g.C + offC : nullptr;
-  uint16_t* __restrict__ C16 = g.C16 ? g.C16 + offC : nullptr;
-  const float* __restrict__ bias = g.bias ? g.bias + offB : nullptr;
-  const float* __restrict__ colscale = g.colscale;
-  const float* __restrict__ R1 = g.R1;
-  const float* __restrict__ R2 = g.R2;
-  const bool vec = ((g.ldc & 3) == 0) && (!R1 || (g.ldr1 & 3) == 0) && (!R2 || (g.ldr2 & 3) == 0);
-  const int nbase = nt * BN + wn * 64 + fq * 4;
-  float bv[4][4], cv[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nbase + j * 16 + r;
-      const int nn = n < g.N ? n : g.N - 1;
-      bv[j][r] = bias ? bias[nn] : 0.f;
-      cv[j][r] = g.out_scale * (colscale ? colscale[nn] : 1.f);
-    }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  // epilogue.  D tile (j,i): lane holds n = nb + 4*(lane>>4) + r (r = 0..3) for m = mb + (lane & 15)
+  fetch_r1(2, q1b[0]);
+  fetch_r1(3, q1b[1]);
+  auto finish_row = [&](int i, const f32x4 (&r1v)[4]) {
     const int m = row0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= row_end) continue;
-    const float rs = g.rowscale ? g.rowscale[m] : 1.f;
-    const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
-    bool keymask = false;
-    if (ACT == ACT_FEAT && g.feat_len) {
-      const int tok = m / g.feat_rpt, slot = m - tok * g.feat_rpt;
-      if (slot >= g.feat_kslot) {
-        const int bb = tok / g.feat_S, t = tok - bb * g.feat_S;
-        keymask = t >= g.feat_len[bb];
-      }
-    }
-    f32x4 q1[4], q2[4];
+    if (m >= row_end) return;
+    f32x4 q2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = nbase + j * 16;
-      q1[j] = (f32x4){0.f, 0.f, 0.f, 0.f}, q2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      q2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!R2) continue;
       if (vec && n + 3 < g.N) {
-        if (R1) q1[j] = *(const f32x4*)(R1 + mr * g.ldr1 + n);
-        if (R2) q2[j] = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
+        q2[j] = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (n + r < g.N) {
-            if (R1) q1[j][r] = R1[mr * g.ldr1 + n + r];
-            if (R2) q2[j][r] = R2[(int64_t)m * g.ldr2 + n + r];
-          }
+          if (n + r < g.N) q2[j][r] = R2[(int64_t)m * g.ldr2 + n + r];
       }
     }
 #pragma unroll
@@ -215,9 +243,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
         } else if constexpr (ACT == ACT_SILU) {
           x = silu(x);
         } else if constexpr (ACT == ACT_FEAT) {
-          x = keymask ? 0.f : 0.1f * expf(fminf(fmaxf(x, -15.f), 15.f));
+          x = keymask[i] ? 0.f : 0.1f * expf(fminf(fmaxf(x, -15.f), 15.f));
         }
-        v[r] = x * (cv[j][r] * rs) + g.r1_scale * q1[j][r] + q2[j][r];
+        v[r] = x * (cv[j][r] * rs[i]) + g.r1_scale * r1v[j][r] + q2[j][r];
       }
       if (vec && n + 3 < g.N) {
         if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -231,7 +259,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
         }
       }
     }
-  }
+  };
+  finish_row(0, q1a[0]);
+  finish_row(1, q1a[1]);
+  finish_row(2, q1b[0]);
+  finish_row(3, q1b[1]);
 }
 
 }  // namespace
@@ -277,7 +309,9 @@ int gemm_bf16(const GemmArgs& a, hipStream_t stream) {
   const int tn = (a.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);
   switch (g_bf16_variant) {
+    case 2: return launch_bf16<64, 3>(a, grid, stream);
     case 3: return launch_bf16<32, 3>(a, grid, stream);
+    case 5: return launch_bf16<64, 4>(a, grid, stream);
     default: return launch_bf16<64, 2>(a, grid, stream);
   }
 }

@@ -152,48 +152,53 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     o.alpha = 0.1f;
     MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, w.qkv, nullptr, o));
   }
-  // shared LN over head_dim, L2 normalise q,k                     (:44-55)
-  MDM_TRY(head_norm(w.qkv, c.M, H, dh, p.hn_w, p.hn_b, c.s));
-  // feature maps 0.1*exp(clamp(z P)), keys masked past length     (:58-74): rows = (token, slot<2H)
-  {
-    GemmArgs g = gemm_defaults(c.prec);
-    g.A = op_f32(w.qkv, dh);
-    g.A.rpg = 2 * H, g.A.gstride = 3 * D;
-    g.W = packed(p.feat);
-    g.M = (int)(c.M * 2 * H), g.N = mf, g.K = dh;
-    g.C = w.phi, g.ldc = mf;
-    g.act = ACT_FEAT;
-    g.feat_len = c.len, g.feat_S = c.S, g.feat_rpt = 2 * H, g.feat_kslot = H;
-    MDM_TRY(gemm(g, c.s));
+  if (c.bf && perf_attn_supported(dh, c.S)) {
+    // throughput mode: LN/L2 -> feature maps -> KV state -> num/den -> LN in ONE kernel per (batch, head)  (:44-90)
+    MDM_TRY(perf_attn(w.qkv, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, (uint16_t*)w.t4, c.s));
+  } else {
+    // shared LN over head_dim, L2 normalise q,k                     (:44-55)
+    MDM_TRY(head_norm(w.qkv, c.M, H, dh, p.hn_w, p.hn_b, c.s));
+    // feature maps 0.1*exp(clamp(z P)), keys masked past length     (:58-74): rows = (token, slot<2H)
+    {
+      GemmArgs g = gemm_defaults(c.prec);
+      g.A = op_f32(w.qkv, dh);
+      g.A.rpg = 2 * H, g.A.gstride = 3 * D;
+      g.W = packed(p.feat);
+      g.M = (int)(c.M * 2 * H), g.N = mf, g.K = dh;
+      g.C = w.phi, g.ldc = mf;
+      g.act = ACT_FEAT;
+      g.feat_len = c.len, g.feat_S = c.S, g.feat_rpt = 2 * H, g.feat_kslot = H;
+      MDM_TRY(gemm(g, c.s));
+    }
+    // KV^T[b,h] (dh x m) = 0.1 * sum_t v[t] (x) kphi[t]              (:77)
+    {
+      GemmArgs g = gemm_defaults(c.prec);
+      g.A = op_f32_kstride(w.qkv + 2 * D, 3 * D);
+      g.A.bs1 = (int64_t)c.S * 3 * D, g.A.bs2 = dh;
+      g.W = op_f32_kstride(w.phi + H * mf, 2 * H * mf);
+      g.W.bs1 = (int64_t)c.S * 2 * H * mf, g.W.bs2 = mf;
+      g.M = dh, g.N = mf, g.K = c.S;
+      g.batch = c.B * H, g.nb2 = H;
+      g.C = w.kvt, g.ldc = mf, g.c_bs1 = (int64_t)H * dh * mf, g.c_bs2 = (int64_t)dh * mf;
+      g.out_scale = 0.1f;
+      MDM_TRY(gemm(g, c.s));
+    }
+    // num = 0.1 * qphi KV                                            (:78) -> t2 (M, D) merged heads
+    {
+      GemmArgs g = gemm_defaults(c.prec);
+      g.A = op_f32(w.phi, 2 * H * mf);
+      g.A.bs1 = (int64_t)c.S * 2 * H * mf, g.A.bs2 = mf;
+      g.W = op_f32(w.kvt, mf);
+      g.W.bs1 = (int64_t)H * dh * mf, g.W.bs2 = (int64_t)dh * mf;
+      g.M = c.S, g.N = dh, g.K = mf;
+      g.batch = c.B * H, g.nb2 = H;
+      g.C = w.t2, g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
+      g.out_scale = 0.1f;
+      MDM_TRY(gemm(g, c.s));
+    }
+    // same-t denominator, divide, LN over head_dim                   (:81-90) -> t4
+    MDM_TRY(den_ln(w.t2, w.phi, c.M, H, dh, p.hn_w, p.hn_b, w.t4, c.bf, c.s));
   }
-  // KV^T[b,h] (dh x m) = 0.1 * sum_t v[t] (x) kphi[t]              (:77)
-  {
-    GemmArgs g = gemm_defaults(c.prec);
-    g.A = op_f32_kstride(w.qkv + 2 * D, 3 * D);
-    g.A.bs1 = (int64_t)c.S * 3 * D, g.A.bs2 = dh;
-    g.W = op_f32_kstride(w.phi + H * mf, 2 * H * mf);
-    g.W.bs1 = (int64_t)c.S * 2 * H * mf, g.W.bs2 = mf;
-    g.M = dh, g.N = mf, g.K = c.S;
-    g.batch = c.B * H, g.nb2 = H;
-    g.C = w.kvt, g.ldc = mf, g.c_bs1 = (int64_t)H * dh * mf, g.c_bs2 = (int64_t)dh * mf;
-    g.out_scale = 0.1f;
-    MDM_TRY(gemm(g, c.s));
-  }
-  // num = 0.1 * qphi KV                                            (:78) -> t2 (M, D) merged heads
-  {
-    GemmArgs g = gemm_defaults(c.prec);
-    g.A = op_f32(w.phi, 2 * H * mf);
-    g.A.bs1 = (int64_t)c.S * 2 * H * mf, g.A.bs2 = mf;
-    g.W = op_f32(w.kvt, mf);
-    g.W.bs1 = (int64_t)H * dh * mf, g.W.bs2 = (int64_t)dh * mf;
-    g.M = c.S, g.N = dh, g.K = mf;
-    g.batch = c.B * H, g.nb2 = H;
-    g.C = w.t2, g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
-    g.out_scale = 0.1f;
-    MDM_TRY(gemm(g, c.s));
-  }
-  // same-t denominator, divide, LN over head_dim                   (:81-90) -> t4
-  MDM_TRY(den_ln(w.t2, w.phi, c.M, H, dh, p.hn_w, p.hn_b, w.t4, c.bf, c.s));
   // proj_out: Linear -> GELU -> Linear                             (:121-126,165)
   {
     LinOpts o;

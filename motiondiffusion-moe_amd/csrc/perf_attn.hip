@@ -1,0 +1,292 @@
+// Fused Performer-style linear attention core (fast_attention.py:29-92) for head_dim = 128, throughput mode.
+// One workgroup (4 waves) per (batch, head); everything between the QKV projection and the output projection
+// happens on chip:
+//   K:  k rows -> LN(dh) -> L2 norm -> bf16 A-fragments in registers -> MFMA with P^T (LDS) -> 0.1*exp(clamp) -> mask
+//       -> kphi^T [m][t] in LDS (the accumulator's 4 consecutive t per lane are one 8-byte store)
+//   V:  v rows -> LN(dh) -> v^T [d][t] in LDS
+//   KV: KV^T [d][m] = 0.1 * sum_t v^T kphi^T   (both operands t-contiguous in LDS: plain ds_read_b128 fragments)
+//   Q:  q rows -> LN -> L2 -> MFMA with P^T with the operands swapped, so the feature accumulator (4 consecutive m per
+//       lane, one t per lane) IS the B operand of the next MFMA after exp + bf16 packing (the k-slot order is matched on
+//       the KV^T side by two 8-byte reads); same-t denominator from kphi^T; num / den; LN(dh); bf16 rows out.
+// LDS: kphi^T and v^T 128 x (TP+8) bf16 each (row stride/16 B odd => conflict-free fragment reads), KV^T 128 x 136;
+// P^T (128 x 136) time-shares the v^T region.  153,600 B at T = 196.
+#include "kernels.h"
+
+namespace mdm {
+namespace {
+
+constexpr int DH = 128, MF = 128, PS = 136;  // PS: padded row stride (elements) of the 128-wide LDS images
+
+typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ frag_t make_frag(const float* x) {
+  u32x4 u = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])};
+  return __builtin_bit_cast(frag_t, u);
+}
+
+__device__ __forceinline__ float quad_sum(float v) {  // across the 4 lanes that share (lane & 15)
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256, 1) void perf_attn_kernel(const float* __restrict__ qkv, const uint16_t* __restrict__ PT,
+                                                           int ldp, const float* __restrict__ hn_w,
+                                                           const float* __restrict__ hn_b, const int* __restrict__ len,
+                                                           int S, int H, uint16_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  uint16_t* smem = (uint16_t*)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int D = H * DH;
+  const int ntile = (S + 15) >> 4, SP = ntile * 16, TP = (S + 31) & ~31, TS = TP + 8;
+  const int vreg = (DH * TS > MF * PS) ? DH * TS : MF * PS;  // v^T region also hosts P^T
+  uint16_t* kT = smem;
+  uint16_t* vT = smem + MF * TS;
+  uint16_t* KV = vT + vreg;
+  uint16_t* PTl = vT;
+  int nvalid = len[b];
+  nvalid = nvalid < S ? nvalid : S;
+
+  // LayerNorm gain/bias at this lane's input positions k = 32*ks + 8*q + j
+  float gw[32], gb[32];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const f32x4 a = *(const f32x4*)(hn_w + 32 * ks + 8 * q), c = *(const f32x4*)(hn_w + 32 * ks + 8 * q + 4);
+    const f32x4 d = *(const f32x4*)(hn_b + 32 * ks + 8 * q), e = *(const f32x4*)(hn_b + 32 * ks + 8 * q + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gw[8 * ks + j] = a[j], gw[8 * ks + 4 + j] = c[j];
+      gb[8 * ks + j] = d[j], gb[8 * ks + 4 + j] = e[j];
+    }
+  }
+
+  auto load_PT = [&]() {
+    for (int i = tid; i < MF * 16; i += 256) {
+      const int row = i >> 4, c = i & 15;
+      *(uint4*)(PTl + row * PS + c * 8) = *(const uint4*)(PT + (int64_t)row * ldp + c * 8);
+    }
+  };
+  // row t0 + r16 of q (0) / k (1) / v (2): LN over head_dim (+ L2 normalise) -> x[32] at k = 32*ks + 8*q + j
+  auto load_norm = [&](int which, int t0, bool l2, float (&x)[32]) {
+    const int t = t0 + r16;
+    const int tc = t < S ? t : S - 1;
+    const float* p = qkv + ((int64_t)(b * S + tc)) * 3 * D + which * D + h * DH + 8 * q;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += x[i];
+    const float mean = quad_sum(s) * (1.f / DH);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      x[i] -= mean;
+      v += x[i] * x[i];
+    }
+    const float rstd = rsqrtf(quad_sum(v) * (1.f / DH) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] = x[i] * rstd * gw[i] + gb[i];
+    if (l2) {
+      float n = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) n += x[i] * x[i];
+      const float inv = 1.f / fmaxf(sqrtf(quad_sum(n)), 1e-12f);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) x[i] *= inv;
+    }
+  };
+
+  load_PT();
+  __syncthreads();
+
+  // ---- K: kphi^T[m][t] ---------------------------------------------------------------------------
+  for (int tile = wid; tile < ntile; tile += 4) {
+    const int t0 = tile * 16;
+    float x[32];
+    load_norm(1, t0, true, x);
+    frag_t a[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a[ks] = make_frag(x + 8 * ks);
+    f32x4 acc[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const frag_t p = *(const frag_t*)(PTl + (16 * mt + r16) * PS + 32 * ks + 8 * q);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], p, acc[mt], 0, 0, 0);  // D[t][m]
+      }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 4 * q + r;
+        v[r] = t < nvalid ? 0.1f * expf(fminf(fmaxf(acc[mt][r], -15.f), 15.f)) : 0.f;  // key mask (:69-74)
+      }
+      *(uint2*)(kT + (16 * mt + r16) * TS + t0 + 4 * q) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    }
+  }
+  __syncthreads();  // kphi^T complete, P^T reads done
+
+  // ---- V: v^T[d][t] ------------------------------------------------------------------------------
+  for (int tile = wid; tile < ntile; tile += 4) {
+    const int t0 = tile * 16, t = t0 + r16;
+    float x[32];
+    load_norm(2, t0, false, x);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        vT[(32 * ks + 8 * q + j) * TS + t] = t < S ? (uint16_t)(pack_bf16(x[8 * ks + j], 0.f) & 0xffff) : (uint16_t)0;
+  }
+  if (TP > SP) {  // zero the K-padding columns of both images
+    for (int i = tid; i < DH * 16; i += 256) {
+      const int row = i >> 4, c = i & 15;
+      kT[row * TS + SP + c] = 0;
+      vT[row * TS + SP + c] = 0;
+    }
+  }
+  __syncthreads();
+
+  // ---- KV^T[d][m] = 0.1 * sum_t v^T[d][t] kphi^T[m][t]  (:77) ----------------------------------------
+  {
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < TP / 32; ++ks) {
+      frag_t a[2], bf[8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *(const frag_t*)(kT + (16 * (2 * wid + i) + r16) * TS + 32 * ks + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bf[j] = *(const frag_t*)(vT + (16 * j + r16) * TS + 32 * ks + 8 * q);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    // D[m][d]: col d = 16j + r16, rows m = 16(2w+i) + 4q + r  ->  KV^T[d][m..m+3]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *(uint2*)(KV + (16 * j + r16) * PS + 16 * (2 * wid + i) + 4 * q) =
+            make_uint2(pack_bf16(0.1f * acc[i][j][0], 0.1f * acc[i][j][1]), pack_bf16(0.1f * acc[i][j][2], 0.1f * acc[i][j][3]));
+  }
+  __syncthreads();  // v^T dead: its region takes P^T again
+  load_PT();
+  __syncthreads();
+
+  // ---- Q: features -> denominator -> num = qphi KV -> LN -> out -------------------------------------
+  for (int tile = wid; tile < ntile; tile += 4) {
+    const int t0 = tile * 16, t = t0 + r16;
+    float x[32];
+    load_norm(0, t0, true, x);
+    frag_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag(x + 8 * ks);
+    f32x4 accf[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) accf[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const frag_t p = *(const frag_t*)(PTl + (16 * mt + r16) * PS + 32 * ks + 8 * q);
+        accf[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p, qf[ks], accf[mt], 0, 0, 0);  // D[m][t]
+      }
+    // lane: t = t0 + r16, m = 16*mt + 4q + r
+    float den = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float f = 0.1f * expf(fminf(fmaxf(accf[mt][r], -15.f), 15.f));
+        accf[mt][r] = f;
+        den += f * bf16_bits_to_f32(kT[(16 * mt + 4 * q + r) * TS + t]);  // same-t dot (:81)
+      }
+    den = fmaxf(quad_sum(den), 1e-6f);
+    f32x4 accn[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) accn[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      // k-slots j=0..3 <-> m = 32s + 4q + j ; j=4..7 <-> m = 32s + 16 + 4q + (j-4)
+      const u32x4 ub = {pack_bf16(accf[2 * s][0], accf[2 * s][1]), pack_bf16(accf[2 * s][2], accf[2 * s][3]),
+                        pack_bf16(accf[2 * s + 1][0], accf[2 * s + 1][1]), pack_bf16(accf[2 * s + 1][2], accf[2 * s + 1][3])};
+      const frag_t bq = __builtin_bit_cast(frag_t, ub);
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const uint2 lo = *(const uint2*)(KV + (16 * dt + r16) * PS + 32 * s + 4 * q);
+        const uint2 hi = *(const uint2*)(KV + (16 * dt + r16) * PS + 32 * s + 16 + 4 * q);
+        const u32x4 ua = {lo.x, lo.y, hi.x, hi.y};
+        accn[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, ua), bq, accn[dt], 0, 0, 0);  // D[d][t]
+      }
+    }
+    // lane: t, d = 16*dt + 4q + r.  out = LN_dh(0.1 * num / den)   (:78,85-90)
+    const float sc = 0.1f / den;
+    float s1 = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        accn[dt][r] *= sc;
+        s1 += accn[dt][r];
+      }
+    const float mean = quad_sum(s1) * (1.f / DH);
+    float s2 = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        accn[dt][r] -= mean;
+        s2 += accn[dt][r] * accn[dt][r];
+      }
+    const float rstd = rsqrtf(quad_sum(s2) * (1.f / DH) + 1e-5f);
+    if (t < S) {
+      uint16_t* orow = out + ((int64_t)(b * S + t)) * D + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const f32x4 w = *(const f32x4*)(hn_w + 16 * dt + 4 * q), bb = *(const f32x4*)(hn_b + 16 * dt + 4 * q);
+        const float y0 = accn[dt][0] * rstd * w[0] + bb[0], y1 = accn[dt][1] * rstd * w[1] + bb[1];
+        const float y2 = accn[dt][2] * rstd * w[2] + bb[2], y3 = accn[dt][3] * rstd * w[3] + bb[3];
+        *(uint2*)(orow + 16 * dt + 4 * q) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool perf_attn_supported(int dh, int S) { return dh == DH && S >= 1 && S <= 224; }
+
+int perf_attn(const float* qkv, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
+              int S, int H, int dh, uint16_t* out, hipStream_t s) {
+  if (!perf_attn_supported(dh, S)) return MDM_ERR_UNSUPPORTED;
+  if (!qkv || !PT || !hn_w || !hn_b || !len || !out || (ldp & 7)) return MDM_ERR_ARG;
+  const int TP = (S + 31) & ~31, TS = TP + 8;
+  const int vreg = (DH * TS > MF * PS) ? DH * TS : MF * PS;
+  const int smem = (MF * TS + vreg + DH * PS) * 2;
+  static int attr = 0;
+  if (smem > attr) {
+    if (hipFuncSetAttribute((const void*)perf_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return MDM_ERR_LAUNCH;
+    attr = smem;
+  }
+  hipLaunchKernelGGL(perf_attn_kernel, dim3(B * H), dim3(256), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+}  // namespace mdm
