@@ -12,7 +12,7 @@
 namespace mdm {
 namespace {
 
-constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int BN = 128, NT = 256;
 
 typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
 
@@ -41,13 +41,16 @@ __device__ __forceinline__ int chunk_logical(int row, int phys) {
   return (phys - 2 * (row >> 2)) & 3;
 }
 
-template <int BK, int NSTAGE, int ACT>
+template <int BM, int BK, int NSTAGE, int ACT>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   constexpr int ROWB = 2 * BK;             // bytes per LDS row
-  constexpr int TILE_B = BM * ROWB;        // bytes per operand per stage
+  constexpr int TILE_A = BM * ROWB, TILE_W = BN * ROWB;  // bytes per operand per stage
+  constexpr int STAGE_B = TILE_A + TILE_W;
   constexpr int RPP = 1024 / ROWB;         // rows per 1-KiB LDS-DMA piece (8 or 16)
-  constexpr int PPW = BM / RPP / 4;        // pieces per wave per operand per stage (4 or 2)
+  constexpr int PPA = BM / RPP / 4;        // A pieces per wave per stage
+  constexpr int PPWW = BN / RPP / 4;       // W pieces per wave per stage
+  constexpr int MI = BM / 32;              // 16-row fragments per wave along M (waves 2x2)
   constexpr int CPR = ROWB / 16;           // 16-B chunks per row
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -82,28 +85,33 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   // per-lane source rows of this wave's LDS-DMA pieces (RPP rows x ROWB bytes each); rows past the edge are
   // clamped to a valid row (their products are discarded in the epilogue): pad, don't mask
   const int sub = lane / CPR;  // row inside the piece
-  const uint16_t* pa[PPW];
-  const uint16_t* pw[PPW];
+  const uint16_t* pa[PPA];
+  const uint16_t* pw[PPWW];
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int tr = (wid * PPW + i) * RPP + sub;  // row inside the tile
+  for (int i = 0; i < PPA; ++i) {
+    const int tr = (wid * PPA + i) * RPP + sub;  // row inside the tile
     const int koff = chunk_logical<BK>(tr, lane % CPR) * 8;
     int r = row0 + tr;
     r = r < row_end ? r : row_end - 1;
     const int64_t src = g.A.gather ? (int64_t)g.A.gather[r] : (int64_t)r;
     pa[i] = (const uint16_t*)g.A.p + offA + src * g.A.ld + koff;
+  }
+#pragma unroll
+  for (int i = 0; i < PPWW; ++i) {
+    const int tr = (wid * PPWW + i) * RPP + sub;
+    const int koff = chunk_logical<BK>(tr, lane % CPR) * 8;
     int n = nt * BN + tr;
     n = n < g.N ? n : g.N - 1;
     pw[i] = (const uint16_t*)g.W.p + offW + (int64_t)n * g.W.ld + koff;
   }
   auto stage = [&](int kt, int buf) {
-    uint8_t* sa = smem + buf * 2 * TILE_B + wid * PPW * 1024;
-    uint8_t* sw = sa + TILE_B;
+    uint8_t* sa = smem + buf * STAGE_B + wid * PPA * 1024;
+    uint8_t* sw = smem + buf * STAGE_B + TILE_A + wid * PPWW * 1024;
     const int k0 = kt * BK;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16(pa[i] + k0, sa + i * 1024);
+    for (int i = 0; i < PPA; ++i) glds16(pa[i] + k0, sa + i * 1024);
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16(pw[i] + k0, sw + i * 1024);
+    for (int i = 0; i < PPWW; ++i) glds16(pw[i] + k0, sw + i * 1024);
   };
 
   // Everything the epilogue reads (bias / column scales / row scales / residuals) is fetched BEFORE the K loop and
@@ -118,10 +126,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   const bool vec = ((g.ldc & 3) == 0) && (!R1 || (g.ldr1 & 3) == 0) && (!R2 || (g.ldr2 & 3) == 0);
   const int fq = lane >> 4;
   const int nbase = nt * BN + wn * 64 + fq * 4;
-  float bv[4][4], cv[4][4], rs[4];
-  f32x4 q1a[2][4], q1b[2][4];  // first residual: rows i = 0,1 prefetched here, rows 2,3 at the top of the epilogue
-  bool keymask[4];
-  int64_t mrow[4];
+  float bv[4][4], cv[4][4], rs[MI];
+  f32x4 q1a[MI / 2][4], q1b[MI / 2][4];  // first residual: rows i = 0,1 prefetched here, rows 2,3 at the top of the epilogue
+  bool keymask[MI];
+  int64_t mrow[MI];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -132,8 +140,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       cv[j][r] = g.out_scale * (colscale ? colscale[nn] : 1.f);
     }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < MI; ++i) {
+    const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
     const bool ok = m < row_end;
     rs[i] = (ok && g.rowscale) ? g.rowscale[m] : 1.f;
     const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     mrow[i] = mr;
   }
   auto fetch_r1 = [&](int i, f32x4 (&dst)[4]) {
-    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+    const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = nbase + j * 16;
@@ -163,12 +171,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       }
     }
   };
-  fetch_r1(0, q1a[0]);
-  fetch_r1(1, q1a[1]);
-
-  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI / 2; ++i) fetch_r1(i, q1a[i]);
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) stage(s, s);
 
-  constexpr int PIECES = 2 * PPW;  // LDS-DMA instructions per wave per K-tile
+  constexpr int PIECES = PPA + PPWW;  // LDS-DMA instructions per wave per K-tile
   const int frow = lane & 15;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once each wave's pieces for it have: wait for all but the younger tiles, then barrier
@@ -191,19 +199,23 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     }
     __builtin_amdgcn_s_barrier();
     if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
-    const uint8_t* sa = smem + (kt % NSTAGE) * 2 * TILE_B;
-    const uint8_t* sw = sa + TILE_B;
+    const uint8_t* sa = smem + (kt % NSTAGE) * STAGE_B;
+    const uint8_t* sw = sa + TILE_A;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      frag_t a[4], b[4];
+      frag_t a[MI], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra = wm * 64 + i * 16 + frow, rb = wn * 64 + i * 16 + frow;
+      for (int i = 0; i < MI; ++i) {
+        const int ra = wm * (BM / 2) + i * 16 + frow;
         a[i] = *(const frag_t*)(sa + ra * ROWB + (chunk_phys<BK>(ra, ks * 4 + fq) << 4));
-        b[i] = *(const frag_t*)(sw + rb * ROWB + (chunk_phys<BK>(rb, ks * 4 + fq) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const int rb = wn * 64 + j * 16 + frow;
+        b[j] = *(const frag_t*)(sw + rb * ROWB + (chunk_phys<BK>(rb, ks * 4 + fq) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);  // D = W A^T: (n, m)
@@ -211,10 +223,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   }
 
   // epilogue.  D tile (j,i): lane holds n = nb + 4*(lane>>4) + r (r = 0..3) for m = mb + (lane & 15)
-  fetch_r1(2, q1b[0]);
-  fetch_r1(3, q1b[1]);
+#pragma unroll
+  for (int i = 0; i < MI / 2; ++i) fetch_r1(MI / 2 + i, q1b[i]);
   auto finish_row = [&](int i, const f32x4 (&r1v)[4]) {
-    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+    const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
     if (m >= row_end) return;
     f32x4 q2[4];
 #pragma unroll
@@ -260,10 +272,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       }
     }
   };
-  finish_row(0, q1a[0]);
-  finish_row(1, q1a[1]);
-  finish_row(2, q1b[0]);
-  finish_row(3, q1b[1]);
+#pragma unroll
+  for (int i = 0; i < MI / 2; ++i) finish_row(i, q1a[i]);
+#pragma unroll
+  for (int i = 0; i < MI / 2; ++i) finish_row(MI / 2 + i, q1b[i]);
 }
 
 }  // namespace
@@ -276,28 +288,31 @@ bool gemm_bf16_eligible(const GemmArgs& a) {
          ((((uintptr_t)a.A.p) | ((uintptr_t)a.W.p)) & 15) == 0 && a.A.rpg == 0;
 }
 
-template <int BK, int NS, int ACT>
-static int launch_bf16_act(const GemmArgs& a, dim3 grid, hipStream_t stream) {
-  constexpr int smem = NS * 2 * BM * 2 * BK;
+template <int BM, int BK, int NS, int ACT>
+static int launch_bf16_act(const GemmArgs& a, hipStream_t stream) {
+  constexpr int smem = NS * (BM + BN) * 2 * BK;
   static bool attr_set = false;
   if (smem > 65536 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BK, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BK, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BK, NS, ACT>), grid, dim3(NT), smem, stream, a);
+  const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
+  const int tn = (a.N + BN - 1) / BN;
+  dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BK, NS, ACT>), grid, dim3(NT), smem, stream, a);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
 
-template <int BK, int NS>
-static int launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+template <int BM, int BK, int NS>
+static int launch_bf16(const GemmArgs& a, hipStream_t stream) {
   switch (a.act) {
-    case ACT_NONE: return launch_bf16_act<BK, NS, ACT_NONE>(a, grid, stream);
-    case ACT_GELU: return launch_bf16_act<BK, NS, ACT_GELU>(a, grid, stream);
-    case ACT_SILU: return launch_bf16_act<BK, NS, ACT_SILU>(a, grid, stream);
-    case ACT_FEAT: return launch_bf16_act<BK, NS, ACT_FEAT>(a, grid, stream);
+    case ACT_NONE: return launch_bf16_act<BM, BK, NS, ACT_NONE>(a, stream);
+    case ACT_GELU: return launch_bf16_act<BM, BK, NS, ACT_GELU>(a, stream);
+    case ACT_SILU: return launch_bf16_act<BM, BK, NS, ACT_SILU>(a, stream);
+    case ACT_FEAT: return launch_bf16_act<BM, BK, NS, ACT_FEAT>(a, stream);
     default: return MDM_ERR_ARG;
   }
 }
@@ -305,15 +320,13 @@ static int launch_bf16(const GemmArgs& a, dim3 grid, hipStream_t stream) {
 int gemm_bf16(const GemmArgs& a, hipStream_t stream) {
   if (!gemm_bf16_eligible(a)) return MDM_ERR_UNSUPPORTED;
   if (!a.C && !a.C16) return MDM_ERR_ARG;
-  const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
-  const int tn = (a.N + BN - 1) / BN;
-  dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);
-  switch (g_bf16_variant) {
-    case 2: return launch_bf16<64, 3>(a, grid, stream);
-    case 3: return launch_bf16<32, 3>(a, grid, stream);
-    case 5: return launch_bf16<64, 4>(a, grid, stream);
-    default: return launch_bf16<64, 2>(a, grid, stream);
-  }
+  // few 128x128 tiles => the launch is a latency chain on <= 2 blocks per CU: halve the tile height so that every
+  // CU holds 3+ independent blocks (variant 1 / 2 force the 128- / 64-row tile for benchmarking)
+  const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + BN - 1) / BN) * a.batch;
+  bool small = !a.goff && tiles128 <= 256;
+  if (g_bf16_variant == 1) small = false;
+  if (g_bf16_variant == 2) small = true;
+  return small ? launch_bf16<64, 64, 2>(a, stream) : launch_bf16<128, 64, 2>(a, stream);
 }
 
 }  // namespace mdm
