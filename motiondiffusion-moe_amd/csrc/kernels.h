@@ -40,6 +40,11 @@ bool perf_attn_supported(int dh, int S);
 int perf_attn(const float* qkv, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s);
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
+// fused text cross-attention cores (xattn.hip), head_dim 128
+bool xattn_supported(int dh, int N);
+int sd_attn(const float* q, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
+            float* out32, hipStream_t s);
+int lin_xattn(const float* ql, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s);
 int col_softmax(float* k, int B, int N, int D, hipStream_t s);
 int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s);
 int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s);

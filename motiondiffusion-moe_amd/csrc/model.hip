@@ -236,17 +236,21 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
   const Work& w = c.w;
   MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, c.bf, nullptr, nullptr, nullptr, 0, c.s));
   MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, w.t3, nullptr));
-  MDM_TRY(head_softmax(w.t3, c.M * H, dh, c.s));  // softmax over head_dim (:248)
-  {
-    GemmArgs g = gemm_defaults(c.prec);  // y[b,s,h,:] = q[b,s,h,:] A[b,h]  (:253), W = A^T rows
-    g.A = op_f32(w.t3, D);
-    g.A.bs1 = (int64_t)c.S * D, g.A.bs2 = dh;
-    g.W = op_f32(at, dh);
-    g.W.bs1 = (int64_t)H * dh * dh, g.W.bs2 = (int64_t)dh * dh;
-    g.M = c.S, g.N = dh, g.K = dh;
-    g.batch = c.B * H, g.nb2 = H;
-    g.C = w.t4, g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
-    MDM_TRY(gemm(g, c.s));
+  if (c.bf && xattn_supported(dh, 1)) {
+    MDM_TRY(lin_xattn(w.t3, at, c.B, c.S, H, dh, w.t4, c.s));  // softmax over head_dim + q A, fused (:248,253)
+  } else {
+    MDM_TRY(head_softmax(w.t3, c.M * H, dh, c.s));  // softmax over head_dim (:248)
+    {
+      GemmArgs g = gemm_defaults(c.prec);  // y[b,s,h,:] = q[b,s,h,:] A[b,h]  (:253), W = A^T rows
+      g.A = op_f32(w.t3, D);
+      g.A.bs1 = (int64_t)c.S * D, g.A.bs2 = dh;
+      g.W = op_f32(at, dh);
+      g.W.bs1 = (int64_t)H * dh * dh, g.W.bs2 = (int64_t)dh * dh;
+      g.M = c.S, g.N = dh, g.K = dh;
+      g.batch = c.B * H, g.nb2 = H;
+      g.C = w.t4, g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
+      MDM_TRY(gemm(g, c.s));
+    }
   }
   return style_apply(c, l.ca_style, w.t4, nullptr, nullptr, nullptr, sc, w.t2, x, 1.f, l.ca_gvec, out);
 }
@@ -313,29 +317,33 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
     o.alpha = 1.f / sqrtf((float)dh);
     MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.sd_q, l.sd_q_b, D, w.t1, nullptr, o));
   }
-  {
-    GemmArgs g = gemm_defaults(c.prec);  // scores[b,h,s,n] = q . k
-    g.A = op_f32(w.t1, D);
-    g.A.bs1 = (int64_t)c.S * D, g.A.bs2 = dh;
-    g.W = op_f32(kc, D);
-    g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
-    g.M = c.S, g.N = N, g.K = dh;
-    g.batch = c.B * H, g.nb2 = H;
-    g.C = w.scr, g.ldc = N, g.c_bs1 = (int64_t)H * c.S * N, g.c_bs2 = (int64_t)c.S * N;
-    MDM_TRY(gemm(g, c.s));
-  }
-  MDM_TRY(row_softmax(w.scr, c.M * H, N, c.s));
-  {
-    GemmArgs g = gemm_defaults(c.prec);  // o[b,s,h,:] = p v
-    g.A = op_f32(w.scr, N);
-    g.A.bs1 = (int64_t)H * c.S * N, g.A.bs2 = (int64_t)c.S * N;
-    g.W = op_f32_kstride(vc, D);
-    g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
-    g.M = c.S, g.N = dh, g.K = N;
-    g.batch = c.B * H, g.nb2 = H;
-    g.C = c.bf ? nullptr : w.t2, g.C16 = c.bf ? (uint16_t*)w.t2 : nullptr;
-    g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
-    MDM_TRY(gemm(g, c.s));
+  if (c.bf && xattn_supported(dh, N)) {
+    MDM_TRY(sd_attn(w.t1, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.s));  // scores, softmax, PV fused
+  } else {
+    {
+      GemmArgs g = gemm_defaults(c.prec);  // scores[b,h,s,n] = q . k
+      g.A = op_f32(w.t1, D);
+      g.A.bs1 = (int64_t)c.S * D, g.A.bs2 = dh;
+      g.W = op_f32(kc, D);
+      g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
+      g.M = c.S, g.N = N, g.K = dh;
+      g.batch = c.B * H, g.nb2 = H;
+      g.C = w.scr, g.ldc = N, g.c_bs1 = (int64_t)H * c.S * N, g.c_bs2 = (int64_t)c.S * N;
+      MDM_TRY(gemm(g, c.s));
+    }
+    MDM_TRY(row_softmax(w.scr, c.M * H, N, c.s));
+    {
+      GemmArgs g = gemm_defaults(c.prec);  // o[b,s,h,:] = p v
+      g.A = op_f32(w.scr, N);
+      g.A.bs1 = (int64_t)H * c.S * N, g.A.bs2 = (int64_t)c.S * N;
+      g.W = op_f32_kstride(vc, D);
+      g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
+      g.M = c.S, g.N = dh, g.K = N;
+      g.batch = c.B * H, g.nb2 = H;
+      g.C = c.bf ? nullptr : w.t2, g.C16 = c.bf ? (uint16_t*)w.t2 : nullptr;
+      g.ldc = D, g.c_bs1 = (int64_t)c.S * D, g.c_bs2 = dh;
+      MDM_TRY(gemm(g, c.s));
+    }
   }
   MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.sd_out, l.sd_out_b, D, w.t3, nullptr));
   MDM_TRY(ln_chain(w.t3, c.M, D, l.sd_ln_w, l.sd_ln_b, w.t4, c.bf, nullptr, nullptr, nullptr, 0, c.s));

@@ -1,0 +1,206 @@
+// Fused text cross-attention cores for head_dim = 128 (throughput mode), one workgroup per (batch, head):
+//   softmax cross attention (fast_attention.py:305-325): o = softmax_n(q k^T) v over N <= 96 text tokens
+//   linear cross attention  (fast_attention.py:248,253):  y = softmax_dh(q) A          with A^T[b,h] cached per text
+// Same register choreography as perf_attn.hip: rows of q are loaded straight into MFMA fragments (lane = row,
+// 8 consecutive k per lane group), products are taken with the operands swapped so that each lane ends up with
+// 4 consecutive output features of ONE row; the score accumulator is reused as the B operand of the value product.
+#include "kernels.h"
+
+namespace mdm {
+namespace {
+
+constexpr int DH = 128, PS = 136, NP = 96, NS = NP + 8;  // NS: row stride (elements) of the v^T image
+
+typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ frag_t make_frag(const float* x) {
+  u32x4 u = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])};
+  return __builtin_bit_cast(frag_t, u);
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+// row (t0 + lane&15) of a (M, D) fp32 matrix, head h: x[32] at k = 32*ks + 8*q + j
+__device__ __forceinline__ void load_row(const float* __restrict__ base, int64_t row, int D, int h, int q, float (&x)[32]) {
+  const float* p = base + row * D + h * DH + 8 * q;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
+  }
+}
+
+template <int NT32>  // ceil(N / 32)
+__global__ __launch_bounds__(256) void sd_attn_kernel(const float* __restrict__ qm, const float* __restrict__ kc,
+                                                      const float* __restrict__ vc, int S, int H, int N,
+                                                      uint16_t* __restrict__ out16, float* __restrict__ out32) {
+  __shared__ __attribute__((aligned(16))) uint16_t kL[NT32 * 32 * PS];  // k [n][d]
+  __shared__ __attribute__((aligned(16))) uint16_t vT[DH * NS];         // v^T [d][n]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
+  for (int i = tid; i < NT32 * 32 * (DH / 4); i += 256) {
+    const int n = i / (DH / 4), c = i - n * (DH / 4);
+    f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+      kv = *(const f32x4*)(kc + ((int64_t)(b * N + n)) * D + h * DH + 4 * c);
+      vv = *(const f32x4*)(vc + ((int64_t)(b * N + n)) * D + h * DH + 4 * c);
+    }
+    *(uint2*)(kL + n * PS + 4 * c) = make_uint2(pack_bf16(kv[0], kv[1]), pack_bf16(kv[2], kv[3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vT[(4 * c + j) * NS + n] = (uint16_t)(pack_bf16(vv[j], 0.f) & 0xffff);
+  }
+  __syncthreads();
+  const int ntile = (S + 15) >> 4;
+  for (int tile = wid; tile < ntile; tile += 4) {
+    const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
+    float x[32];
+    load_row(qm, (int64_t)b * S + tc, D, h, q, x);
+    frag_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag(x + 8 * ks);
+    f32x4 sc[2 * NT32];
+#pragma unroll
+    for (int nt = 0; nt < 2 * NT32; ++nt) sc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2 * NT32; ++nt) {
+        const frag_t kf = *(const frag_t*)(kL + (16 * nt + r16) * PS + 32 * ks + 8 * q);
+        sc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[nt], 0, 0, 0);  // D[n][t]
+      }
+    // lane: t, n = 16*nt + 4q + r.  softmax over n (no text mask in the reference, :317-320)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 2 * NT32; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (16 * nt + 4 * q + r >= N) sc[nt][r] = -INFINITY;
+        mx = fmaxf(mx, sc[nt][r]);
+      }
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2 * NT32; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sc[nt][r] = expf(sc[nt][r] - mx);
+        sum += sc[nt][r];
+      }
+    const float inv = 1.f / quad_sum(sum);
+    f32x4 o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NT32; ++s) {
+      const u32x4 ub = {pack_bf16(sc[2 * s][0] * inv, sc[2 * s][1] * inv), pack_bf16(sc[2 * s][2] * inv, sc[2 * s][3] * inv),
+                        pack_bf16(sc[2 * s + 1][0] * inv, sc[2 * s + 1][1] * inv),
+                        pack_bf16(sc[2 * s + 1][2] * inv, sc[2 * s + 1][3] * inv)};
+      const frag_t pf = __builtin_bit_cast(frag_t, ub);
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const uint2 lo = *(const uint2*)(vT + (16 * dt + r16) * NS + 32 * s + 4 * q);
+        const uint2 hi = *(const uint2*)(vT + (16 * dt + r16) * NS + 32 * s + 16 + 4 * q);
+        const u32x4 ua = {lo.x, lo.y, hi.x, hi.y};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, ua), pf, o[dt], 0, 0, 0);  // D[d][t]
+      }
+    }
+    if (t < S) {
+      const int64_t off = ((int64_t)b * S + t) * D + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        if (out16) *(uint2*)(out16 + off + 16 * dt + 4 * q) = make_uint2(pack_bf16(o[dt][0], o[dt][1]), pack_bf16(o[dt][2], o[dt][3]));
+        if (out32) *(f32x4*)(out32 + off + 16 * dt + 4 * q) = o[dt];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lin_xattn_kernel(const float* __restrict__ ql, const float* __restrict__ at, int S,
+                                                        int H, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint16_t aL[DH * PS];  // A^T [l][d]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
+  const float* ab = at + (int64_t)blockIdx.x * DH * DH;
+  for (int i = tid; i < DH * (DH / 4); i += 256) {
+    const int l = i / (DH / 4), c = i - l * (DH / 4);
+    const f32x4 v = *(const f32x4*)(ab + l * DH + 4 * c);
+    *(uint2*)(aL + l * PS + 4 * c) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+  }
+  __syncthreads();
+  const int ntile = (S + 15) >> 4;
+  for (int tile = wid; tile < ntile; tile += 4) {
+    const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
+    float x[32];
+    load_row(ql, (int64_t)b * S + tc, D, h, q, x);
+    float mx = -INFINITY;  // softmax over head_dim (:248)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) mx = fmaxf(mx, x[i]);
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      x[i] = expf(x[i] - mx);
+      sum += x[i];
+    }
+    const float inv = 1.f / quad_sum(sum);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] *= inv;
+    frag_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag(x + 8 * ks);
+    f32x4 y[8];
+#pragma unroll
+    for (int lt = 0; lt < 8; ++lt) y[lt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int lt = 0; lt < 8; ++lt) {
+        const frag_t af = *(const frag_t*)(aL + (16 * lt + r16) * PS + 32 * ks + 8 * q);
+        y[lt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, qf[ks], y[lt], 0, 0, 0);  // D[l][t]
+      }
+    if (t < S) {
+      float* orow = out + ((int64_t)b * S + t) * D + h * DH;
+#pragma unroll
+      for (int lt = 0; lt < 8; ++lt) *(f32x4*)(orow + 16 * lt + 4 * q) = y[lt];
+    }
+  }
+}
+
+}  // namespace
+
+bool xattn_supported(int dh, int N) { return dh == DH && N >= 1 && N <= NP; }
+
+int sd_attn(const float* q, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
+            float* out32, hipStream_t s) {
+  if (!xattn_supported(dh, N)) return MDM_ERR_UNSUPPORTED;
+  if (!q || !kc || !vc || (!out16 && !out32)) return MDM_ERR_ARG;
+  const dim3 grid(B * H), block(256);
+  if (N <= 32) {
+    hipLaunchKernelGGL(sd_attn_kernel<1>, grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);
+  } else if (N <= 64) {
+    hipLaunchKernelGGL(sd_attn_kernel<2>, grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);
+  } else {
+    hipLaunchKernelGGL(sd_attn_kernel<3>, grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);
+  }
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int lin_xattn(const float* ql, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s) {
+  if (dh != DH) return MDM_ERR_UNSUPPORTED;
+  if (!ql || !at || !out) return MDM_ERR_ARG;
+  hipLaunchKernelGGL(lin_xattn_kernel, dim3(B * H), dim3(256), 0, s, ql, at, S, H, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+}  // namespace mdm

@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mdm_hip.h declares (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, pkg
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mdm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = pkg("_lib")
+    if not os.path.exists(L.LIB_PATH):
+        pkg("build").build(verbose=False)
+    lib = L.lib()
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in mdm_hip.h but not exported"
+    assert set(L.EXPORTS) == set(names), (set(L.EXPORTS) ^ set(names))
+    assert lib.mdm_version().startswith(b"mdm_hip")
+
+
+def test_struct_mirrors_match_c_layout(tmp_path):
+    """ctypes mirrors in _lib.py must agree with the C structs (compiled with g++ on the fly)."""
+    L = pkg("_lib")
+    src = tmp_path / "sz.cpp"
+    src.write_text('#include "mdm_hip.h"\n#include <cstdio>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(MdmOperand),sizeof(MdmGemmDesc),sizeof(MdmPacked),sizeof(MdmStyle),sizeof(MdmPerformer),"
+                   "sizeof(MdmLayer),sizeof(MdmModel),sizeof(MdmTextCache));}\n")
+    exe = tmp_path / "sz"
+    import subprocess
+    subprocess.check_call(["g++", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    ours = [C.sizeof(x) for x in (L.Operand, L.GemmDesc, L.Packed, L.Style, L.Performer, L.Layer, L.Model, L.TextCache)]
+    assert sizes == ours
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad descriptors before touching the device."""
+    L = pkg("_lib")
+    lib = L.lib()
+    assert lib.mdm_gemm(None, None) == 1
+    d = L.GemmDesc()
+    d.M = d.N = d.K = 8
+    d.batch = d.nb2 = 1
+    assert lib.mdm_gemm(C.byref(d), None) == 1  # null operands
+    assert lib.mdm_workspace_bytes(None, 1, 2, 1) == -1
+    assert lib.mdm_cfg_posterior_step(None, None, None, None, C.c_int64(0), None, 0, None, 0, C.c_float(1.0), 0, None, None, None) == 1

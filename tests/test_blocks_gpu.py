@@ -1,0 +1,95 @@
+"""GPU: each decoder block through mdm_block_forward against the oracle's restatement of the same block, in both
+precision modes, at the real head_dim (128) with ragged lengths and S not a multiple of the tile sizes."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT, build_module, load_golden, rel_inf, pkg
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import denoiser_ref as R  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = {3: 1e-3, 1: 3e-2}
+
+
+def _setup(B, S, N, precision):
+    g, meta = load_golden("fwd_small_dims")
+    m, (sd, eph, proj, mcfg) = build_module(meta, precision=precision)
+    synth = pkg("synth")
+    D, Dt, H, E = 512, 256, 4, 8
+    h = synth.uniform_pm1((B, S, D), "blk.h", S) * 1.5
+    emb = synth.uniform_pm1((B, D), "blk.emb", S)
+    xf = synth.uniform_pm1((B, N, Dt), "blk.xf", N) * 1.7
+    length = torch.tensor([S, max(1, S - 13)][:B] + [S] * max(0, B - 2))
+    pre = "decoder_blocks_low.0.module"
+    sc = []
+    for slot, sp in (("local_style", pre + ".dual_self_attn.local_attn.style_block"),
+                     ("global_style", pre + ".dual_self_attn.global_attn.style_block"),
+                     ("cross_style", pre + ".cross_attn.base_ca.proj_out"), ("ffn_style", pre + ".ffn.proj_out")):
+        w, b = eph["low.0." + slot]
+        e = F.linear(emb, w, b)
+        sc.append(F.linear(F.silu(e), sd[sp + ".emb_layers.1.weight"], sd[sp + ".emb_layers.1.bias"]))
+    sc = torch.stack(sc)  # (4, B, 2D)
+    return m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E)
+
+
+def _run_block(m, block, h, sc, length, xf, forced=None):
+    L = pkg("_lib")
+    pm = m.pack()
+    B, S, D = h.shape
+    tcache = m.prepare_text(xf.cuda())
+    ws = m._workspace(B, S, xf.shape[1])
+    hd, scd, ld = h.cuda().contiguous(), sc.cuda().contiguous(), length.to(torch.int32).cuda()
+    out = torch.empty_like(hd)
+    fr = forced.to(torch.int32).cuda().contiguous() if forced is not None else None
+    L.check(L.lib().mdm_block_forward(C.byref(pm.model), C.c_int32(0), C.c_int32(block), C.byref(tcache["tc"]),
+                                      C.c_void_p(hd.data_ptr()), C.c_void_p(scd.data_ptr()), C.c_void_p(ld.data_ptr()),
+                                      C.c_int32(B), C.c_int32(S), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                      C.c_int64(ws.numel()), C.c_void_p(L.ptr(fr)), C.c_int32(m.precision),
+                                      C.c_void_p(L.stream_ptr())))
+    return out.cpu()
+
+
+@pytest.mark.parametrize("precision", [3, 1])
+@pytest.mark.parametrize("S,N", [(40, 6), (98, 28), (196, 85)])
+def test_blocks_match_oracle(S, N, precision):
+    B = 2
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, precision)
+    L = pkg("_lib")
+    mask = R.src_mask(S, length)
+    with torch.no_grad():
+        ref_dual = R.dual_self_attention(h, emb, mask, sd, pre + ".dual_self_attn", H, eph, proj, "low.0")
+        ref_cross = R.gated_cross_attention(h, xf, emb, sd, pre + ".cross_attn", H, eph["low.0.cross_style"])
+        trace = {}
+        ref_moe = R.moe_ffn(h, emb, sd, pre + ".ffn", E, eph["low.0.ffn_style"], None, trace)
+        ref_sd = R.softmax_cross_ffn(h, xf, sd, pre + ".sd_cross_attn", H)
+    forced = torch.stack([trace[f"{pre}.ffn.branches.{b}.top2_idx"] for b in range(2)])  # (2, M, 2)
+    errs = {
+        "dual": rel_inf(_run_block(m, L.BLOCK_DUAL, h, sc, length, xf), ref_dual),
+        "cross": rel_inf(_run_block(m, L.BLOCK_CROSS, h, sc, length, xf), ref_cross),
+        "moe": rel_inf(_run_block(m, L.BLOCK_MOE, h, sc, length, xf, forced if precision == 1 else None), ref_moe),
+        "sdcross": rel_inf(_run_block(m, L.BLOCK_SDCROSS, h, sc, length, xf), ref_sd),
+    }
+    print(f"S={S} N={N} precision={precision}:", {k: f"{v:.2e}" for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v < TOL[precision]}
+    assert not bad, bad
+
+
+def test_free_routing_flip_budget_bf16():
+    """Throughput mode with FREE routing: gate logits are fp32 (router kernel) computed from an fp32 LayerNorm, so the
+    top-2 choice only differs from the oracle's where p2 - p3 is within fp32 noise: none expected at this size."""
+    B, S, N = 2, 98, 6
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, 1)
+    L = pkg("_lib")
+    with torch.no_grad():
+        ref_moe = R.moe_ffn(h, emb, sd, pre + ".ffn", E, eph["low.0.ffn_style"], None, None)
+    out = _run_block(m, L.BLOCK_MOE, h, sc, length, xf)
+    tok_err = (out - ref_moe).abs().amax(-1) / ref_moe.abs().amax()
+    flipped = int((tok_err > 0.1).sum())
+    print("tokens with O(1) change (routing flips):", flipped, "of", B * S)
+    assert flipped <= 1

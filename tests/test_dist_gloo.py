@@ -1,0 +1,63 @@
+"""CPU, world_size 2 (gloo): batch sharding + the path's single all_gather give world-size independent results."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, pkg
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_sampler(local_shape, kw, x_T, step_noise):
+    # a stand-in "denoising loop": per-sample arithmetic only (samples never interact)
+    x = x_T.clone()
+    for n in step_noise:
+        x = 0.9 * x + 0.1 * n * kw["length"].view(-1, 1, 1).float() + kw["xf_proj"].sum(-1).view(-1, 1, 1)
+    return x
+
+
+def _worker(rank, world, port, B, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dmod = pkg("dist")
+    kw = {"length": torch.arange(B) + 3, "xf_proj": torch.arange(B * 2, dtype=torch.float32).view(B, 2),
+          "text": [f"t{i}" for i in range(B)], "scalar": 5}
+    y = dmod.sample_sharded(_fake_sampler, (B, 4, 3), kw, seed=7, steps_with_noise=3)
+    if rank == 0:
+        torch.save(y, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [4, 5])
+def test_sharded_sampling_is_world_size_invariant(tmp_path, B):
+    dmod = pkg("dist")
+    kw = {"length": torch.arange(B) + 3, "xf_proj": torch.arange(B * 2, dtype=torch.float32).view(B, 2),
+          "text": [f"t{i}" for i in range(B)], "scalar": 5}
+    single = dmod.sample_sharded(_fake_sampler, (B, 4, 3), kw, seed=7, steps_with_noise=3)
+    out = str(tmp_path / "y.pt")
+    mp.spawn(_worker, args=(2, _free_port(), B, out), nprocs=2, join=True)
+    assert torch.equal(torch.load(out), single)
+
+
+def test_shard_ranges_cover_batch():
+    dmod = pkg("dist")
+    for B in (1, 7, 32, 33):
+        for w in (1, 2, 3, 8):
+            r = [dmod.shard_range(B, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == B and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+    sk = dmod.shard_kwargs({"a": torch.arange(6), "t": list("abcdef"), "s": 3}, 2, 5)
+    assert sk["a"].tolist() == [2, 3, 4] and sk["t"] == ["c", "d", "e"] and sk["s"] == 3

@@ -1,0 +1,120 @@
+"""CPU: host-side logic of the drop-in layer (no kernels run): schedule tables, layouts, packing transforms,
+module surface, loud failure without a GPU."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, golden_state, pkg
+
+
+def test_diffusion_tables_match_reference_golden():
+    D = pkg("diffusion")
+    g, meta = load_golden("loops_tiny")
+    d = D.GaussianDiffusion(betas=D.get_named_beta_schedule("linear", meta["steps_cfg"]),
+                            model_mean_type=D.ModelMeanType.EPSILON, model_var_type=D.ModelVarType.FIXED_SMALL,
+                            loss_type=D.LossType.MSE)
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                 "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                 "posterior_mean_coef1", "posterior_mean_coef2"):
+        assert np.array_equal(getattr(d, name), g["tables/" + name].numpy()), name
+    tab = d.schedule_table()
+    assert tab.shape == (7, meta["steps_cfg"]) and tab.dtype == np.float32
+    assert np.array_equal(tab[2], g["tables/posterior_mean_coef1"].numpy().astype(np.float32))
+    d1000 = D.GaussianDiffusion(betas=D.get_named_beta_schedule("linear", 1000), model_mean_type=D.ModelMeanType.EPSILON,
+                                model_var_type=D.ModelVarType.FIXED_SMALL, loss_type=D.LossType.MSE)
+    assert np.array_equal(d1000.posterior_mean_coef2, g["tables1000/posterior_mean_coef2"].numpy())
+
+
+def test_unsupported_sampler_configs_raise():
+    D = pkg("diffusion")
+    d = D.GaussianDiffusion(betas=D.get_named_beta_schedule("linear", 50), model_mean_type=D.ModelMeanType.START_X,
+                            model_var_type=D.ModelVarType.FIXED_SMALL, loss_type=D.LossType.MSE)
+    with pytest.raises(NotImplementedError):
+        d.p_sample_loop_with_cfg(None, (1, 2, 3))
+    d = D.GaussianDiffusion(betas=D.get_named_beta_schedule("linear", 50), model_mean_type=D.ModelMeanType.EPSILON,
+                            model_var_type=D.ModelVarType.LEARNED, loss_type=D.LossType.MSE)
+    with pytest.raises(NotImplementedError):
+        d.schedule_table()
+    with pytest.raises(NotImplementedError):
+        D.get_named_beta_schedule("nope", 10)
+
+
+def test_module_state_dict_layout_and_cpu_refusal():
+    """Same keys/shapes as the reference dump; forward on CPU tensors fails loudly (no fallback path)."""
+    import json
+    from conftest import GOLDEN
+    T, L = pkg("transformer"), pkg("_lib")
+    lay = json.load(open(os.path.join(GOLDEN, "state_dict_layout.json")))["tools_L2"]
+    m = T.MotionTransformer(263, **lay["kwargs"])
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == lay["keys"]
+    assert sum(p.numel() for p in m.parameters()) == lay["n_params"]
+    # reference init semantics: zero gates/out head, xavier'd Performer "zero" layers are NOT zero
+    sd = m.state_dict()
+    assert float(sd["out.weight"].abs().max()) == 0.0
+    assert float(sd["decoder_blocks_low.0.module.ffn.branches.0.moe.gate.weight"].abs().max()) == 0.0
+    assert float(sd["decoder_blocks_low.0.module.ffn.proj_out.out_layers.2.weight"].abs().max()) == 0.0
+    assert float(sd["decoder_blocks_low.0.module.dual_self_attn.local_attn.style_block.out_layers.2.weight"].abs().max()) > 0
+    x = torch.zeros(1, 4, 263)
+    with pytest.raises(L.MdmError):
+        m(x, torch.zeros(1, dtype=torch.long), torch.tensor([4]), xf_proj=torch.zeros(1, 128), xf_out=torch.zeros(1, 3, 128))
+    with pytest.raises(L.MdmError):
+        m.encode_text(["a"], "cpu")
+    assert m.generate_src_mask(4, torch.tensor([2, 4])).tolist() == [[1, 1, 0, 0], [1, 1, 1, 1]]
+    # load_state_dict(strict=False) tolerates the reference's extra text_encoder.* keys (ddpm_trainer.py:286-288)
+    extra = dict(sd)
+    extra["text_encoder.prompt_tokens"] = torch.zeros(1, 8, 1024)
+    m.load_state_dict(extra, strict=False)
+
+
+def test_kernel_layout_transforms_are_exact():
+    """packing.kernel_layout: conv-as-linear weight reshapes reproduce F.conv1d / F.conv_transpose1d; stacking orders."""
+    P, synth = pkg("packing"), pkg("synth")
+    g, meta = load_golden("fwd_tiny")
+    sd, eph, proj, mcfg = golden_state(meta)
+    cfg = dict(mcfg, ff_size=128, text_latent_dim=32, input_feats=263, num_frames=16)
+    lay = P.kernel_layout(sd, cfg, eph, proj)
+    D = 64
+    h = torch.randn(2, 8, D)
+    ref = F.conv1d(h.permute(0, 2, 1), sd["downsample.weight"], sd["downsample.bias"], stride=2).permute(0, 2, 1)
+    ours = h.reshape(2 * 4, 2 * D) @ lay["W:down"].T + lay["V:down_b"]
+    assert torch.allclose(ours.reshape(2, 4, D), ref, atol=1e-5)
+    hl = torch.randn(2, 4, D)
+    ref = F.conv_transpose1d(hl.permute(0, 2, 1), sd["upsample.weight"], sd["upsample.bias"], stride=2).permute(0, 2, 1)
+    ours = (hl.reshape(8, D) @ lay["W:up"].T + lay["V:up_b2"]).reshape(2, 8, D)
+    assert torch.allclose(ours, ref, atol=1e-5)
+    E, F_ = 4, 128
+    assert lay["W:L0.w1"].shape == (2 * E * F_, D) and lay["W:L0.w2"].shape == (2 * E * D, F_)
+    assert torch.equal(lay["W:L0.w1"][(1 * E + 2) * F_:(1 * E + 3) * F_],
+                       sd["decoder_blocks_low.0.module.ffn.branches.1.moe.experts.2.0.weight"])
+    assert torch.equal(lay["W:L1.local.qkv"][D:2 * D], sd["decoder_blocks_high.0.module.dual_self_attn.local_attn.key.weight"])
+    Te = 4 * D
+    assert lay["W:style_eph"].shape == (8 * Te, D) and lay["W:style_emb"].shape == (8 * 2 * D, Te)
+    assert torch.equal(lay["W:style_eph"][2 * Te:3 * Te], eph["low.0.cross_style"][0])
+    assert torch.equal(lay["W:style_emb"][7 * 2 * D:], sd["decoder_blocks_high.0.module.ffn.proj_out.emb_layers.1.weight"])
+    assert torch.equal(lay["W:L0.global.feat"], proj["low.0.global"].t())
+
+
+def test_synth_is_platform_exact_and_seeded():
+    synth = pkg("synth")
+    a = synth.uniform_pm1((4, 5), "x", 3)
+    assert torch.equal(a, synth.uniform_pm1((4, 5), "x", 3)) and not torch.equal(a, synth.uniform_pm1((4, 5), "x", 4))
+    assert float(a.abs().max()) < 1.0
+    names = synth.ephemeral_names(2, True)
+    assert names[0] == "text_proj" and len(names) == 1 + 2 * 2 * 4 and names[1] == "low.0.local_style"
+    assert synth.synth_projection("p", 128, 0).shape == (128, 128)
+
+
+def test_trainer_surface():
+    Tr, T = pkg("trainer"), pkg("transformer")
+    m = T.MotionTransformer(263, num_frames=8, latent_dim=64, ff_size=64, num_layers=1, num_heads=4, text_latent_dim=32,
+                            moe_num_experts=2)
+    args = types.SimpleNamespace(device=torch.device("cpu"), diffusion_steps=50, is_train=False)
+    tr = Tr.DDPMTrainer(args, m)
+    assert tr.cfg_scale == 7.5 and tr.diffusion.num_timesteps == 50
+    assert tr._model() is m
+    with pytest.raises(NotImplementedError):
+        tr.train()
