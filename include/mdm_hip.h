@@ -143,6 +143,19 @@ typedef struct MdmTextCache {
   int32_t B, N;
 } MdmTextCache;
 
+/* Optional per-loop stem cache: the time-embedding chain (time.py:15-31 -> time_embed -> time_proj -> gated_fusion.proj_time,
+ * transformer.py:318-320, gate.py:16) depends only on the integer timestep, and gated_fusion.proj_text(text_proj(xf_proj))
+ * only on the text: both are tabulated once per sampling loop instead of being recomputed by 8 tiny GEMMs every step. */
+typedef struct MdmStemCache {
+  const float* time_table; /* [steps, D], row t = proj_time(...(t)) */
+  const float* gx;         /* [B, D] = proj_text(text_proj(xf_proj)) */
+  int32_t steps;
+} MdmStemCache;
+
+/* Fill time_table [steps, D] (t = 0..steps-1) and gx [B, D]; either output may be NULL.  ws as for (B=128, T=2, N=1). */
+int mdm_stem_cache_build(const MdmModel* m, int32_t steps, float* time_table, const float* xf_proj, int32_t B, float* gx,
+                         void* ws, int64_t ws_bytes, int32_t precision, void* stream);
+
 /* Bytes of scratch mdm_denoiser_forward / the block entry points need for (B, T, N). */
 int64_t mdm_workspace_bytes(const MdmModel* m, int32_t B, int32_t T, int32_t N);
 
@@ -152,10 +165,12 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
 
 /* MotionTransformer.forward (transformer.py:291-361) with text already encoded:
  * x [B,T,feats], timesteps int64 [B], length int32 [B], xf_proj [B,Dt] -> out [B,T,feats].
- * forced_routing: NULL, or int32 [2L][2][B*S_layer][2] expert indices (parity tests). */
+ * forced_routing: NULL, or int32 [2L][2][B*S_layer][2] expert indices (parity tests); trace: NULL or per-block dumps;
+ * stem: NULL or a cache built by mdm_stem_cache_build for integer timesteps in [0, steps). */
 int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float* x, const int64_t* timesteps,
                          const int32_t* length, const float* xf_proj, int32_t B, int32_t T, float* out, void* ws,
-                         int64_t ws_bytes, const int32_t* forced_routing, float* trace, int32_t precision, void* stream);
+                         int64_t ws_bytes, const int32_t* forced_routing, float* trace, const MdmStemCache* stem,
+                         int32_t precision, void* stream);
 
 /* One decoder layer / its four blocks on h [B,S,D] in place semantics (out may alias nothing);
  * sc = the layer's 4 style (scale|shift) rows [4, B, 2D]; len int32 [B] (already halved for the low scale). */

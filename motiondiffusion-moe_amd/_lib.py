@@ -88,6 +88,10 @@ class TextCache(C.Structure):
                 ("N", C.c_int32)]
 
 
+class StemCache(C.Structure):
+    _fields_ = [("time_table", C.c_void_p), ("gx", C.c_void_p), ("steps", C.c_int32)]
+
+
 BLOCK_DUAL, BLOCK_CROSS, BLOCK_MOE, BLOCK_SDCROSS, BLOCK_LAYER = 0, 1, 2, 3, 4
 TAB_ROWS = 7  # sqrt_recip_acp, sqrt_recipm1_acp, coef1, coef2, post_logvar_clipped, acp, acp_prev
 
@@ -111,7 +115,7 @@ def lib():
 
 # every symbol include/mdm_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mdm_version", "mdm_gemm", "mdm_pack_bf16", "mdm_workspace_bytes", "mdm_text_cache_build",
-           "mdm_denoiser_forward", "mdm_block_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
+           "mdm_denoiser_forward", "mdm_stem_cache_build", "mdm_block_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
            "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant"]
 
 

@@ -323,7 +323,7 @@ int gemm_bf16(const GemmArgs& a, hipStream_t stream) {
   // few 128x128 tiles => the launch is a latency chain on <= 2 blocks per CU: halve the tile height so that every
   // CU holds 3+ independent blocks (variant 1 / 2 force the 128- / 64-row tile for benchmarking)
   const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + BN - 1) / BN) * a.batch;
-  bool small = !a.goff && tiles128 <= 256;
+  bool small = !a.goff && (tiles128 <= 256 || a.M <= 64);
   if (g_bf16_variant == 1) small = false;
   if (g_bf16_variant == 2) small = true;
   return small ? launch_bf16<64, 64, 2>(a, stream) : launch_bf16<128, 64, 2>(a, stream);

@@ -391,9 +391,10 @@ int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, float* x, uin
 }
 
 // fused time/text embedding + every stylization block's (scale|shift)  (transformer.py:313-321, stylization.py:22-27)
-int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj, float* emb_out, float* sc_out) {
+// gt = gated_fusion.proj_time(time_proj(time_embed(learnable_time_embed(t))))  [B, D] -> dst   (transformer.py:318-320)
+int stem_time_branch(const Ctx& c, const int64_t* timesteps, int B, float* dst) {
   const MdmModel& m = *c.m;
-  const int D = m.D, Te = 4 * D, B = c.B, nblk = 8 * m.L;
+  const int D = m.D, Te = 4 * D;
   const Work& w = c.w;
   LinOpts silu_o;
   silu_o.act = ACT_SILU;
@@ -403,22 +404,56 @@ int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj
   MDM_TRY(linear(c, act_f32(w.s_a), B, D, m.te0, m.te0_b, Te, w.s_b, nullptr, silu_o));
   MDM_TRY(linear(c, act_f32(w.s_b), B, Te, m.te2, m.te2_b, Te, w.s_c, nullptr));
   MDM_TRY(linear(c, act_f32(w.s_c), B, Te, m.tproj, m.tproj_b, D, w.s_a, nullptr));
-  MDM_TRY(linear(c, act_f32(w.s_a), B, D, m.gf_time, m.gf_time_b, D, w.s_b, nullptr));  // t
+  return linear(c, act_f32(w.s_a), B, D, m.gf_time, m.gf_time_b, D, dst, nullptr);
+}
+
+// gx = gated_fusion.proj_text([text_proj](xf_proj))  [B, D] -> dst      (transformer.py:313-315, gate.py:17)
+int stem_text_branch(const Ctx& c, const float* xf_proj, int B, float* dst) {
+  const MdmModel& m = *c.m;
   const float* tp = xf_proj;
-  if (m.Dt != D) {  // the per-call random text_proj (transformer.py:313-315), captured
+  if (m.Dt != m.D) {  // the per-call random text_proj, captured
     if (!m.text_proj.hi) return MDM_ERR_ARG;
-    MDM_TRY(linear(c, act_f32(xf_proj), B, m.Dt, m.text_proj, m.text_proj_b, D, w.s_c, nullptr));
-    tp = w.s_c;
+    MDM_TRY(linear(c, act_f32(xf_proj), B, m.Dt, m.text_proj, m.text_proj_b, m.D, c.w.s_c, nullptr));
+    tp = c.w.s_c;
   }
-  MDM_TRY(linear(c, act_f32(tp), B, D, m.gf_text, m.gf_text_b, D, w.s_a, nullptr));  // x
-  MDM_TRY(gated_mix(w.s_b, w.s_a, (int64_t)B * D, w.s_c, c.s));
-  MDM_TRY(linear(c, act_f32(w.s_c), B, D, m.gf_post0, m.gf_post0_b, D, w.s_a, nullptr, silu_o));
+  return linear(c, act_f32(tp), B, m.D, m.gf_text, m.gf_text_b, m.D, dst, nullptr);
+}
+
+// fused time/text embedding + every stylization block's (scale|shift)  (transformer.py:313-321, stylization.py:22-27)
+int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj, const MdmStemCache* sc_cache,
+                    float* emb_out, float* sc_out) {
+  const MdmModel& m = *c.m;
+  const int D = m.D, Te = 4 * D, B = c.B, nblk = 8 * m.L;
+  const Work& w = c.w;
+  LinOpts silu_o;
+  silu_o.act = ACT_SILU;
+  // fused = sigmoid(t + x) * t + (1 - sigmoid) * x                  (gate.py:18-20) -> mix (fp32, or bf16 in throughput mode)
+  float* mix = w.s_b;
+  if (sc_cache && sc_cache->time_table && sc_cache->gx) {
+    MDM_TRY(gated_mix_gather(sc_cache->time_table, timesteps, sc_cache->steps, sc_cache->gx, B, D, c.bf ? nullptr : mix,
+                             c.bf ? (uint16_t*)mix : nullptr, c.s));
+  } else {
+    MDM_TRY(stem_time_branch(c, timesteps, B, w.s_b));
+    MDM_TRY(stem_text_branch(c, xf_proj, B, w.s_a));
+    MDM_TRY(gated_mix(w.s_b, w.s_a, (int64_t)B * D, w.s_c, c.s));
+    if (c.bf) {
+      MDM_TRY(to_bf16(w.s_c, (int64_t)B * D, (uint16_t*)w.s_b, c.s));
+    } else {
+      mix = w.s_c;
+    }
+  }
+  MDM_TRY(linear_to_act(c, act_of(c, mix), B, D, m.gf_post0, m.gf_post0_b, D, w.s_a, silu_o));
   float* emb = emb_out ? emb_out : w.emb;
-  MDM_TRY(linear(c, act_f32(w.s_a), B, D, m.gf_post2, m.gf_post2_b, D, emb, nullptr));
+  MDM_TRY(linear(c, act_of(c, w.s_a), B, D, m.gf_post2, m.gf_post2_b, D, emb, c.bf ? (uint16_t*)w.s_c : nullptr));
   // all 8L blocks at once: e1 = SiLU(emb Weph^T + beph) [B, 8L*Te]; sc[j] = e1[:, j] W1_j^T + b1_j [8L, B, 2D]
-  MDM_TRY(linear(c, act_f32(emb), B, D, m.style_eph, m.style_eph_b, nblk * Te, w.e1, nullptr, silu_o));
+  MDM_TRY(linear_to_act(c, c.bf ? act_bf16((uint16_t*)w.s_c) : act_f32(emb), B, D, m.style_eph, m.style_eph_b, nblk * Te,
+                        w.e1, silu_o));
   GemmArgs g = gemm_defaults(c.prec);
-  g.A = op_f32(w.e1, (int64_t)nblk * Te);
+  if (c.bf) {
+    g.A.p = w.e1, g.A.ld = (int64_t)nblk * Te, g.A.kind = OP_BF16_ROW;
+  } else {
+    g.A = op_f32(w.e1, (int64_t)nblk * Te);
+  }
   g.A.bs1 = Te;
   g.W = packed(m.style_emb);
   g.W.bs1 = (int64_t)2 * D * m.style_emb.ld;
@@ -492,12 +527,39 @@ int mdm_stem_embeddings(const MdmModel* m, const int64_t* timesteps, const float
   c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B;
   c.w = carve(*m, B, 2, 1, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
-  return stem_embeddings(c, timesteps, xf_proj, emb_out, sc_out);
+  return stem_embeddings(c, timesteps, xf_proj, nullptr, emb_out, sc_out);
+}
+
+int mdm_stem_cache_build(const MdmModel* m, int32_t steps, float* time_table, const float* xf_proj, int32_t B, float* gx,
+                         void* ws, int64_t ws_bytes, int32_t precision, void* stream) {
+  MDM_TRY(check_model(m));
+  if (!ws || (time_table && steps <= 0) || (gx && (!xf_proj || B <= 0))) return MDM_ERR_ARG;
+  constexpr int CH = 128;
+  Ctx c = {};
+  // tabulated in the fp32-grade arithmetic regardless of the run mode: it is computed once per loop
+  c.m = m, c.s = (hipStream_t)stream, c.prec = 3, c.bf = false, c.B = CH;
+  (void)precision;
+  c.w = carve(*m, CH, 2, 1, ws);
+  if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
+  int64_t* ts = (int64_t*)c.w.hid;  // scratch for the timestep ramp
+  if (time_table)
+    for (int t0 = 0; t0 < steps; t0 += CH) {
+      const int n = steps - t0 < CH ? steps - t0 : CH;
+      MDM_TRY(iota_i64(ts, n, t0, c.s));
+      MDM_TRY(stem_time_branch(c, ts, n, time_table + (int64_t)t0 * m->D));
+    }
+  if (gx)
+    for (int b0 = 0; b0 < B; b0 += CH) {
+      const int n = B - b0 < CH ? B - b0 : CH;
+      MDM_TRY(stem_text_branch(c, xf_proj + (int64_t)b0 * m->Dt, n, gx + (int64_t)b0 * m->D));
+    }
+  return MDM_OK;
 }
 
 int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float* x, const int64_t* timesteps,
                          const int32_t* length, const float* xf_proj, int32_t B, int32_t T, float* out, void* ws,
-                         int64_t ws_bytes, const int32_t* forced_routing, float* trace, int32_t precision, void* stream) {
+                         int64_t ws_bytes, const int32_t* forced_routing, float* trace, const MdmStemCache* stem,
+                         int32_t precision, void* stream) {
   MDM_TRY(check_model(m));
   if (!tc || !x || !timesteps || !length || !xf_proj || !out || !ws || B <= 0 || T <= 0) return MDM_ERR_ARG;
   if (T % 2 || T > m->num_frames) return MDM_ERR_ARG;  // odd T breaks the U-shape (transformer.py:223-224,353)
@@ -510,7 +572,7 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
   const int D = m->D, L = m->L;
   const int64_t Mfull = (int64_t)B * T, Mlow = Mfull / 2;
   const int64_t scl = (int64_t)4 * B * 2 * D;  // (scale|shift) floats per layer
-  MDM_TRY(stem_embeddings(c, timesteps, xf_proj, nullptr, w.sc));
+  MDM_TRY(stem_embeddings(c, timesteps, xf_proj, stem, nullptr, w.sc));
   // h = joint_embed(x) + sequence_embedding[:T]                     (transformer.py:324-326)
   {
     LinOpts o;

@@ -461,6 +461,27 @@ __global__ void gated_mix_kernel(const float* __restrict__ t, const float* __res
   out[i] = g * tv + (1.f - g) * xv;
 }
 
+// same with t looked up in a per-timestep table (stem cache) and an optional bf16 copy of the result
+__global__ void gated_mix_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ ts, int steps,
+                                        const float* __restrict__ x, int B, int D, float* __restrict__ out,
+                                        uint16_t* __restrict__ out16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, c = i - b * D;
+  int64_t t = ts[b];
+  t = t < 0 ? 0 : (t >= steps ? steps - 1 : t);
+  const float tv = table[t * D + c], xv = x[i];
+  const float g = 1.f / (1.f + expf(-(tv + xv)));
+  const float v = g * tv + (1.f - g) * xv;
+  if (out) out[i] = v;
+  if (out16) out16[i] = (uint16_t)(pack_bf16(v, 0.f) & 0xffff);
+}
+
+__global__ void iota_i64_kernel(int64_t* dst, int64_t n, int64_t start) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = start + i;
+}
+
 // gate vector of the gated cross attention: gvec[c] = sigmoid(gate[c]) * sigmoid(adaptive_gate)
 // (fast_attention.py:256-257,271-272 folded: x + sg*(x + sa*style - x) = x + sg*sa*style)
 __global__ void xattn_gate_kernel(const float* __restrict__ gate, const float* __restrict__ ag, int D,
@@ -642,6 +663,19 @@ int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s) {
 
 int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s) {
   hipLaunchKernelGGL(gated_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, x, n, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int gated_mix_gather(const float* table, const int64_t* ts, int steps, const float* x, int B, int D, float* out,
+                     uint16_t* out16, hipStream_t s) {
+  hipLaunchKernelGGL(gated_mix_gather_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, table, ts, steps, x, B, D, out, out16);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int iota_i64(int64_t* dst, int64_t n, int64_t start, hipStream_t s) {
+  hipLaunchKernelGGL(iota_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, start);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

@@ -224,6 +224,9 @@ class _StepRunner:
         self.ts = torch.zeros(self.R, dtype=torch.int64, device=self.dev)
         self.tab = diff._device_table(self.dev)
         self.graph = None
+        # time-embedding chain tabulated per timestep + text half of the gated fusion: once per loop, not per step
+        self.stem = model.stem_cache(diff.num_timesteps, self.xp) if hasattr(model, "stem_cache") and \
+            getattr(model, "ephemeral_mode", "frozen") == "frozen" else None
 
     # one step on the current stream: reads self.xx[:B] (x_t), writes x_{t-1} back into it
     def _step(self, use_noise: bool):
@@ -233,7 +236,10 @@ class _StepRunner:
         if self.R == 2 * B:
             self.xx[B:].copy_(x)
         L.check(lib.mdm_fill_i64(C.c_void_p(self.ts.data_ptr()), C.c_int64(self.R), C.c_void_p(self.t_dev.data_ptr()), s))
-        self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps)
+        if self.stem is not None:
+            self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps, stem_cache=self.stem)
+        else:
+            self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps)
         noise = C.c_void_p(self.noise.data_ptr() if use_noise else 0)
         steps = C.c_int32(self.d.num_timesteps)
         if self.mode == "ddim":

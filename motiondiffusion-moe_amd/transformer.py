@@ -121,6 +121,7 @@ class MotionTransformer(nn.Module):
         """Forget packed weights / caches (call after mutating parameters in place)."""
         self._packed = None
         self._text_cache = None
+        self._time_table = None
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -281,10 +282,33 @@ class MotionTransformer(nn.Module):
         self._text_cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out), "B": B, "N": N}
         return self._text_cache
 
+    def stem_cache(self, steps: int, xf_proj: torch.Tensor):
+        """Per-loop stem cache (include/mdm_hip.h: MdmStemCache): the time-embedding chain tabulated for every integer
+        timestep of a ``steps``-long schedule (cached per module) + the text half of the gated fusion for this batch."""
+        pm = self.pack()
+        dev, D = self.device, self.latent_dim
+        key = (steps, id(pm))
+        if getattr(self, "_time_table", None) is None or self._time_table[0] != key:
+            self._time_table = (key, torch.empty((steps, D), dtype=torch.float32, device=dev))
+            fill_table = True
+        else:
+            fill_table = False
+        table = self._time_table[1]
+        xp = xf_proj.detach().to(device=dev, dtype=torch.float32).contiguous()
+        gx = torch.empty((xp.shape[0], D), dtype=torch.float32, device=dev)
+        ws = self._workspace(128, 2, 1)
+        L.check(L.lib().mdm_stem_cache_build(C.byref(pm.model), C.c_int32(steps), C.c_void_p(table.data_ptr() if fill_table else 0),
+                                             C.c_void_p(xp.data_ptr()), C.c_int32(xp.shape[0]), C.c_void_p(gx.data_ptr()),
+                                             C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
+                                             C.c_void_p(L.stream_ptr())), "mdm_stem_cache_build")
+        sc = L.StemCache()
+        sc.time_table, sc.gx, sc.steps = table.data_ptr(), gx.data_ptr(), steps
+        return {"sc": sc, "keep": (table, gx)}
+
     @torch.no_grad()
     def forward(self, x: torch.Tensor, timesteps: torch.Tensor, length: torch.Tensor,
                 text: Optional[List[str]] = None, xf_proj=None, xf_out=None, *, forced_routing=None,
-                trace: bool = False, out: Optional[torch.Tensor] = None):
+                trace: bool = False, out: Optional[torch.Tensor] = None, stem_cache=None):
         if not x.is_cuda:
             raise L.MdmError("MotionTransformer.forward needs GPU tensors: the denoiser runs on HIP kernels only")
         B, T, Fe = x.shape
@@ -317,6 +341,7 @@ class MotionTransformer(nn.Module):
             C.byref(pm.model), C.byref(tcache["tc"]), C.c_void_p(x.data_ptr()), C.c_void_p(ts.data_ptr()),
             C.c_void_p(ln.data_ptr()), C.c_void_p(xp.data_ptr()), C.c_int32(B), C.c_int32(T), C.c_void_p(out.data_ptr()),
             C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(L.ptr(fr)), C.c_void_p(L.ptr(tr)),
+            C.byref(stem_cache["sc"]) if stem_cache is not None else None,
             C.c_int32(self.precision), C.c_void_p(L.stream_ptr())), "mdm_denoiser_forward")
         if trace:
             return out, tr
