@@ -32,7 +32,7 @@ struct Work {
   float *xa, *xb, *h0, *t1, *t2, *t3, *t4, *t5, *qkv, *phi, *kvt, *scr, *f1, *hn, *hid, *y2;
   uint16_t *xa16, *xb16, *h016;
   int *top_idx, *perm, *pos4, *hist, *goff, *cursor, *len_low;
-  float *top_val, *rowscale;
+  float *top_val, *rowscale, *uimp;
   // stem (B rows)
   float *s_a, *s_b, *s_c, *emb, *e1, *sc, *gvtmp;
   // text cache scratch
@@ -59,7 +59,7 @@ Work carve(const MdmModel& m, int B, int T, int N, void* ws) {
   w.y2 = b.take<float>(4 * M * D);
   w.top_idx = b.take<int>(4 * M), w.top_val = b.take<float>(4 * M);
   w.perm = b.take<int>(4 * M), w.rowscale = b.take<float>(4 * M), w.pos4 = b.take<int>(4 * M);
-  w.hist = b.take<int>(2 * m.E), w.goff = b.take<int>(2 * m.E + 1), w.cursor = b.take<int>(2 * m.E);
+  w.hist = b.take<int>(512 * 32), w.uimp = b.take<float>(512 * 64), w.goff = b.take<int>(2 * m.E + 1), w.cursor = b.take<int>(2 * m.E);
   w.len_low = b.take<int>(B);
   const int64_t smax = Te > 2 * D ? Te : 2 * D;
   w.s_a = b.take<float>(B * smax), w.s_b = b.take<float>(B * smax), w.s_c = b.take<float>(B * smax);
@@ -267,7 +267,7 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     p.gate_w[b] = l.gate_w[b], p.gate_b[b] = l.gate_b[b];
     p.usage[b] = l.usage[b], p.importance[b] = l.importance[b];
   }
-  p.hn = w.hn, p.hn_bf16 = c.bf, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.forced_idx = forced;
+  p.hn = w.hn, p.hn_bf16 = c.bf, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.uimp = w.uimp, p.forced_idx = forced;
   MDM_TRY(moe_route(x, c.M, D, E, p, w.goff, w.cursor, w.perm, w.rowscale, w.pos4, c.s));
   {
     GemmArgs g = gemm_defaults(c.prec);  // hidden = GELU(LN_b(x)[routed rows] W1_e^T + b1_e)

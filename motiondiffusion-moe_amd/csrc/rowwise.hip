@@ -251,23 +251,178 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  if (threadIdx.x < 2 * E) {
-    const int g = threadIdx.x, br = g / E, e = g - br * E;
-    if (s_hist[g]) atomicAdd(&p.hist[g], s_hist[g]);
-    if (p.usage[br] && s_imp[g] != 0.f) {
-      if (s_usage[g] != 0.f) atomicAdd(&p.usage[br][e], s_usage[g]);
-      atomicAdd(&p.importance[br][e], s_imp[g]);
-    }
+  if (threadIdx.x < 2 * E) {  // per-block partials, summed by moe_offsets_kernel: no global atomics at all
+    const int g = threadIdx.x;
+    p.hist[blockIdx.x * 32 + g] = s_hist[g];
+    p.uimp[blockIdx.x * 64 + g] = s_usage[g];
+    p.uimp[blockIdx.x * 64 + 32 + g] = s_imp[g];
   }
 }
 
-__global__ void moe_offsets_kernel(const int* __restrict__ hist, int G, int* __restrict__ goff, int* __restrict__ cursor) {
+// Router, 16 lanes per token (4 tokens per wave): one set of LayerNorm statistics serves both branches, the gate
+// matrices of both branches sit in LDS, and the 2E logits are reduced with 4-step group shuffles (the one-token-per-
+// wave version above spends its time in 2E full-wave reductions).  Requires D % 64 == 0.
+template <int NV>  // float4 per lane: D = 64 * NV
+__global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict__ x, int64_t M, int D, int E,
+                                                         MoeGateParams p) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];  // [2][E][D] gate weights, then counters
+  float* gw = gsm;
+  int* s_hist = (int*)(gsm + 2 * E * D);
+  float* s_usage = (float*)(s_hist + 32);
+  float* s_imp = s_usage + 32;
+  for (int i = threadIdx.x; i < 2 * E * D / 4; i += 256) {
+    const int br = (4 * i) / (E * D), off = 4 * i - br * E * D;
+    *(f32x4*)(gw + 4 * i) = *(const f32x4*)(p.gate_w[br] + off);
+  }
+  if (threadIdx.x < 32) s_hist[threadIdx.x] = 0, s_usage[threadIdx.x] = 0.f, s_imp[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int l16 = threadIdx.x & 15;
+  const int64_t tpb = 16;  // tokens per block iteration
+  for (int64_t base = blockIdx.x * tpb; base < M; base += (int64_t)gridDim.x * tpb) {
+    const int64_t row = base + (threadIdx.x >> 4);
+    const bool ok = row < M;
+    const int64_t rc = ok ? row : M - 1;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      v[c] = *(const f32x4*)(x + rc * D + 4 * (l16 + 16 * c));
+      s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    }
+    const float mean = group_sum<16>(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      v[c] = (f32x4){v[c][0] - mean, v[c][1] - mean, v[c][2] - mean, v[c][3] - mean};
+      q += v[c][0] * v[c][0] + v[c][1] * v[c][1] + v[c][2] * v[c][2] + v[c][3] * v[c][3];
+    }
+    const float rstd = rsqrtf(group_sum<16>(q) / D + 1e-5f);
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+      float logit[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) logit[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const int k = 4 * (l16 + 16 * c);
+        const f32x4 w = *(const f32x4*)(p.ln_w[br] + k), b = *(const f32x4*)(p.ln_b[br] + k);
+        const f32x4 h = {v[c][0] * rstd * w[0] + b[0], v[c][1] * rstd * w[1] + b[1], v[c][2] * rstd * w[2] + b[2],
+                         v[c][3] * rstd * w[3] + b[3]};
+        if (ok) {
+          if (p.hn_bf16) {
+            *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_bf16(h[0], h[1]), pack_bf16(h[2], h[3]));
+          } else {
+            *(f32x4*)((float*)p.hn + ((int64_t)br * M + row) * D + k) = h;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (e < E) {
+            const f32x4 g = *(const f32x4*)(gw + (br * E + e) * D + k);
+            logit[e] += h[0] * g[0] + h[1] * g[1] + h[2] * g[2] + h[3] * g[3];
+          }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (e < E) {
+          logit[e] = group_sum<16>(logit[e]) + p.gate_b[br][e];
+          mx = fmaxf(mx, logit[e]);
+        }
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        logit[e] = e < E ? expf(logit[e] - mx) : 0.f;
+        den += logit[e];
+      }
+      int i1 = 0, i2 = -1;
+      float v1 = -1.f, v2 = -1.f;
+      if (p.forced_idx) {
+        i1 = p.forced_idx[((int64_t)br * M + rc) * 2 + 0];
+        i2 = p.forced_idx[((int64_t)br * M + rc) * 2 + 1];
+        v1 = v2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = logit[e] / den;
+          v1 = e == i1 ? pe : v1;
+          v2 = e == i2 ? pe : v2;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = logit[e] / den;
+          if (e < E) {
+            if (pe > v1) {
+              v2 = v1, i2 = i1;
+              v1 = pe, i1 = e;
+            } else if (pe > v2) {
+              v2 = pe, i2 = e;
+            }
+          }
+        }
+      }
+      if (ok && l16 == 0) {
+        const int64_t o = ((int64_t)br * M + row) * 2;
+        p.top_idx[o] = i1, p.top_idx[o + 1] = i2;
+        p.top_val[o] = v1, p.top_val[o + 1] = v2;
+        atomicAdd(&s_hist[br * E + i1], 1);
+        atomicAdd(&s_hist[br * E + i2], 1);
+        atomicAdd(&s_usage[br * E + i1], 1.f);
+        atomicAdd(&s_imp[br * E + i1], v1);
+        atomicAdd(&s_imp[br * E + i2], v2);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * E) {  // per-block partials, summed by moe_offsets_kernel: no global atomics at all
+    const int g = threadIdx.x;
+    p.hist[blockIdx.x * 32 + g] = s_hist[g];
+    p.uimp[blockIdx.x * 64 + g] = s_usage[g];
+    p.uimp[blockIdx.x * 64 + 32 + g] = s_imp[g];
+  }
+}
+
+// sums the per-block partial counters, builds the slab offsets, zeroes the cursors and folds the usage / importance
+// increments into the module's persistent buffers (single writer, deterministic)
+__global__ __launch_bounds__(1024) void moe_offsets_kernel(const int* __restrict__ hist_part,
+                                                            const float* __restrict__ uimp_part, int nparts, int E,
+                                                            int* __restrict__ goff, int* __restrict__ cursor,
+                                                            MoeGateParams p) {
+  __shared__ int sh[32][33];
+  __shared__ float su[32][33], si[32][33];
+  __shared__ int tot[32];
+  const int g = threadIdx.x & 31, c = threadIdx.x >> 5, G = 2 * E;  // 32 counters x 32 part-chunks
+  int h = 0;
+  float u = 0.f, im = 0.f;
+  if (g < G) {
+#pragma unroll 4
+    for (int b = c; b < nparts; b += 32) {  // independent loads: all in flight together
+      h += hist_part[b * 32 + g];
+      u += uimp_part[b * 64 + g];
+      im += uimp_part[b * 64 + 32 + g];
+    }
+  }
+  sh[c][g] = h, su[c][g] = u, si[c][g] = im;
+  __syncthreads();
+  if (threadIdx.x < G) {
+    int ht = 0;
+    float ut = 0.f, it = 0.f;
+    for (int k = 0; k < 32; ++k) ht += sh[k][g], ut += su[k][g], it += si[k][g];  // fixed order: deterministic
+    tot[g] = ht;
+    cursor[g] = 0;
+    const int br = g / E, e = g - br * E;
+    if (p.usage[br]) {
+      p.usage[br][e] += ut;
+      p.importance[br][e] += it;
+    }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     int s = 0;
-    for (int g = 0; g < G; ++g) {
-      goff[g] = s;
-      cursor[g] = 0;
-      s += hist[g];
+    for (int i = 0; i < G; ++i) {
+      goff[i] = s;
+      s += tot[i];
     }
     goff[G] = s;
   }
@@ -594,13 +749,35 @@ int style_in(const float* x, int64_t M, int D, int S, const float* pw, const flo
 int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, int* goff, int* cursor, int* perm,
               float* rowscale, int* pos4, hipStream_t s) {
   if (M <= 0) return MDM_OK;
-  if (E < 2 || E > 16 || !x || !p.hn || !p.hist || !p.top_idx || !p.top_val) return MDM_ERR_ARG;
-  if (hipMemsetAsync(p.hist, 0, sizeof(int) * 2 * E, s) != hipSuccess) return MDM_ERR_LAUNCH;
-  const int gate_grid = row_grid(M) > 1024 ? 1024 : row_grid(M);
+  if (E < 2 || E > 16 || !x || !p.hn || !p.hist || !p.uimp || !p.top_idx || !p.top_val) return MDM_ERR_ARG;
+  int nparts = 0;
+  if (D % 64 == 0 && D <= 1024) {
+    const int smem = 2 * E * D * 4 + 3 * 32 * 4;
+    int64_t nb = (M + 15) / 16;
+    const int grid = (int)(nb > 512 ? 512 : nb);
+    nparts = grid;
+    static int attr_done = 0;
+    if (smem > 65536 && smem > attr_done) {
+      const void* fn = D == 1024 ? (const void*)moe_gate16_kernel<16> : (const void*)moe_gate16_kernel<8>;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return MDM_ERR_LAUNCH;
+      attr_done = smem;
+    }
+    switch (D / 64) {
+      case 1: hipLaunchKernelGGL(moe_gate16_kernel<1>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
+      case 2: hipLaunchKernelGGL(moe_gate16_kernel<2>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
+      case 4: hipLaunchKernelGGL(moe_gate16_kernel<4>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
+      case 8: hipLaunchKernelGGL(moe_gate16_kernel<8>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
+      case 16: hipLaunchKernelGGL(moe_gate16_kernel<16>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
+      default: return MDM_ERR_UNSUPPORTED;
+    }
+  } else {
+  const int gate_grid = row_grid(M) > 512 ? 512 : row_grid(M);
+  nparts = gate_grid;
 #define CALL(NE, VEC) hipLaunchKernelGGL((moe_gate_kernel<NE, VEC>), dim3(gate_grid), dim3(256), 0, s, x, M, D, E, p)
   MDM_ROW_DISPATCH(D, CALL);
 #undef CALL
-  hipLaunchKernelGGL(moe_offsets_kernel, dim3(1), dim3(64), 0, s, p.hist, 2 * E, goff, cursor);
+  }
+  hipLaunchKernelGGL(moe_offsets_kernel, dim3(1), dim3(1024), 0, s, p.hist, p.uimp, nparts, E, goff, cursor, p);
   const int64_t total = 4 * M;
   int blocks = (int)((total + 255) / 256);
   hipLaunchKernelGGL(moe_assign_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, p.top_idx, p.top_val, M, E,
