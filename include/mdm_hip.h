@@ -208,6 +208,8 @@ int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
 
 /* tuning knob for benchmarks: selects the (BK, stages) variant of the bf16 throughput GEMM (0 = default) */
 int mdm_set_gemm_variant(int variant);
+/* diagnostic: s_memtime stamps of block 0 of the last bf16 GEMM launched with feat_S == -77 (host copy, synchronises) */
+int mdm_debug_stamps(uint64_t* out16);
 
 const char* mdm_version(void);
 

@@ -23,9 +23,11 @@ __global__ void pack_bf16_kernel(const float* __restrict__ src, int64_t ld_src, 
 }  // namespace
 }  // namespace mdm
 
-namespace mdm { extern int g_bf16_variant; }
+namespace mdm { extern int g_bf16_variant; int debug_stamps(unsigned long long* out); }
 
 extern "C" {
+
+int mdm_debug_stamps(uint64_t* out16) { return mdm::debug_stamps((unsigned long long*)out16); }
 
 int mdm_set_gemm_variant(int v) {
   mdm::g_bf16_variant = v;

@@ -21,6 +21,16 @@ __device__ __forceinline__ void glds16(const void* g, uint8_t* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+__device__ unsigned long long g_stamps[16];
+#define MDM_STAMP(i)                                                             \
+  do {                                                                       \
+    if (dbg) {                                                               \
+      unsigned long long t__;                                                \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); \
+      if (threadIdx.x == 0) g_stamps[i] = t__;                               \
+    }                                                                        \
+  } while (0)
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -54,6 +64,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   constexpr int CPR = ROWB / 16;           // 16-B chunks per row
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
+  const bool dbg = (g.feat_S == -77) && blockIdx.x == 0;
+  MDM_STAMP(0);
 
   const int ntn = (g.N + BN - 1) / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -114,22 +126,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     for (int i = 0; i < PPWW; ++i) glds16(pw[i] + k0, sw + i * 1024);
   };
 
-  // Everything the epilogue reads (bias / column scales / row scales / residuals) is fetched BEFORE the K loop and
-  // rides in registers: at K = 512 the loop is only 8 tiles long and an epilogue that starts with a dependent
-  // global round trip per row was a third of the block's latency.  Outputs never alias these inputs.
+  // column / row constants of this lane's outputs, fetched before the K loop (they ride in 40 registers)
   float* __restrict__ C = g.C ? g.C + offC : nullptr;
   uint16_t* __restrict__ C16 = g.C16 ? g.C16 + offC : nullptr;
   const float* __restrict__ bias = g.bias ? g.bias + offB : nullptr;
   const float* __restrict__ colscale = g.colscale;
   const float* __restrict__ R1 = g.R1;
   const float* __restrict__ R2 = g.R2;
-  const bool vec = ((g.ldc & 3) == 0) && (!R1 || (g.ldr1 & 3) == 0) && (!R2 || (g.ldr2 & 3) == 0);
   const int fq = lane >> 4;
   const int nbase = nt * BN + wn * 64 + fq * 4;
   float bv[4][4], cv[4][4], rs[MI];
-  f32x4 q1a[MI / 2][4], q1b[MI / 2][4];  // first residual: rows i = 0,1 prefetched here, rows 2,3 at the top of the epilogue
   bool keymask[MI];
-  int64_t mrow[MI];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -144,7 +151,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
     const bool ok = m < row_end;
     rs[i] = (ok && g.rowscale) ? g.rowscale[m] : 1.f;
-    const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
     keymask[i] = false;
     if (ok && ACT == ACT_FEAT && g.feat_len) {
       const int tok = m / g.feat_rpt, slot = m - tok * g.feat_rpt;
@@ -153,26 +159,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
         keymask[i] = t >= g.feat_len[bb];
       }
     }
-    mrow[i] = mr;
   }
-  auto fetch_r1 = [&](int i, f32x4 (&dst)[4]) {
-    const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = nbase + j * 16;
-      dst[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (!R1 || m >= row_end) continue;
-      if (vec && n + 3 < g.N) {
-        dst[j] = *(const f32x4*)(R1 + mrow[i] * g.ldr1 + n);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < g.N) dst[j][r] = R1[mrow[i] * g.ldr1 + n + r];
-      }
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < MI / 2; ++i) fetch_r1(i, q1a[i]);
 
   f32x4 acc[MI][4];
 #pragma unroll
@@ -181,9 +168,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
+  MDM_STAMP(1);
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) stage(s, s);
+  MDM_STAMP(2);
 
   constexpr int PIECES = PPA + PPWW;  // LDS-DMA instructions per wave per K-tile
   const int frow = lane & 15;
@@ -198,6 +187,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       wait_vm<0>();
     }
     __builtin_amdgcn_s_barrier();
+    if (kt == 0) MDM_STAMP(3);
     if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
     const uint8_t* sa = smem + (kt % NSTAGE) * STAGE_B;
     const uint8_t* sw = sa + TILE_A;
@@ -222,31 +212,39 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     }
   }
 
-  // epilogue.  D tile (j,i): lane holds n = nb + 4*(lane>>4) + r (r = 0..3) for m = mb + (lane & 15)
+  MDM_STAMP(4);
+  // Epilogue in two passes through the (now idle) LDS ring:
+  //  1. registers -> LDS: bias, activation, scales applied; D tile (j,i) lane holds n = nb + 4*(lane>>4) + r for
+  //     m = mb + (lane & 15) -> one 16-B write, 16-B chunks of a row XOR-swizzled by the row index;
+  //  2. LDS -> HBM by full rows (a wave instruction covers two whole 512-B rows): residuals are read and outputs
+  //     written as complete cache lines instead of 64-B pieces of 16 different rows.
+  // residual rows of pass 2 are requested NOW (the accumulators' registers are about to die): their latency hides
+  // behind pass 1 and the barrier instead of being paid once per row group
+  const bool vec = ((g.ldc & 3) == 0) && (!R1 || (g.ldr1 & 3) == 0) && (!R2 || (g.ldr2 & 3) == 0);
+  const int cl = tid & 31, n = nt * BN + 4 * cl;
+  const bool fast = vec && (nt * BN + BN <= g.N);
+  constexpr int NR = BM / 8;
+  f32x4 q1[NR], q2[NR];
+  if (fast) {
 #pragma unroll
-  for (int i = 0; i < MI / 2; ++i) fetch_r1(MI / 2 + i, q1b[i]);
-  auto finish_row = [&](int i, const f32x4 (&r1v)[4]) {
-    const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
-    if (m >= row_end) return;
-    f32x4 q2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = nbase + j * 16;
-      q2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (!R2) continue;
-      if (vec && n + 3 < g.N) {
-        q2[j] = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < g.N) q2[j][r] = R2[(int64_t)m * g.ldr2 + n + r];
+    for (int k = 0; k < NR; ++k) {
+      const int m = row0 + (tid >> 5) + 8 * k;
+      q1[k] = (f32x4){0.f, 0.f, 0.f, 0.f}, q2[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < row_end) {
+        const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
+        if (R1) q1[k] = *(const f32x4*)(R1 + mr * g.ldr1 + n);
+        if (R2) q2[k] = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
       }
     }
+  }
+  __syncthreads();  // every wave is done with the last K tile
+  float* stg = (float*)smem;  // [BM][128] fp32
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int ml = wm * (BM / 2) + i * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = nbase + j * 16;
-      if (n >= g.N) continue;
-      float v[4];
+      f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = g.alpha * (acc[i][j][r] + bv[j][r]);
@@ -257,28 +255,52 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
         } else if constexpr (ACT == ACT_FEAT) {
           x = keymask[i] ? 0.f : 0.1f * expf(fminf(fmaxf(x, -15.f), 15.f));
         }
-        v[r] = x * (cv[j][r] * rs[i]) + g.r1_scale * r1v[j][r] + q2[j][r];
+        v[r] = x * (cv[j][r] * rs[i]);
       }
-      if (vec && n + 3 < g.N) {
-        if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
-        if (C16) *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-      } else {
+      const int chunk = wn * 16 + j * 4 + fq;
+      *(f32x4*)(stg + ml * 128 + ((chunk ^ (ml & 31)) << 2)) = v;
+    }
+  }
+  __syncthreads();
+  if (fast) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r >= g.N) break;
-          if (C) C[(int64_t)m * g.ldc + n + r] = v[r];
-          if (C16) C16[(int64_t)m * g.ldc + n + r] = (uint16_t)(pack_bf16(v[r], 0.f) & 0xffff);
-        }
+    for (int k = 0; k < NR; ++k) {
+      const int ml = (tid >> 5) + 8 * k, m = row0 + ml;
+      if (m >= row_end) continue;
+      f32x4 v = *(const f32x4*)(stg + ml * 128 + ((cl ^ (ml & 31)) << 2));
+      v[0] += g.r1_scale * q1[k][0] + q2[k][0], v[1] += g.r1_scale * q1[k][1] + q2[k][1];
+      v[2] += g.r1_scale * q1[k][2] + q2[k][2], v[3] += g.r1_scale * q1[k][3] + q2[k][3];
+      if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;
+      if (C16) *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    }
+  } else {
+    for (int k = 0; k < NR; ++k) {  // ragged N edge / unaligned leading dimensions: element-wise
+      const int ml = (tid >> 5) + 8 * k, m = row0 + ml;
+      if (m >= row_end || n >= g.N) continue;
+      const f32x4 v = *(const f32x4*)(stg + ml * 128 + ((cl ^ (ml & 31)) << 2));
+      const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r >= g.N) break;
+        float x = v[r];
+        if (R1) x += g.r1_scale * R1[mr * g.ldr1 + n + r];
+        if (R2) x += R2[(int64_t)m * g.ldr2 + n + r];
+        if (C) C[(int64_t)m * g.ldc + n + r] = x;
+        if (C16) C16[(int64_t)m * g.ldc + n + r] = (uint16_t)(pack_bf16(x, 0.f) & 0xffff);
       }
     }
-  };
-#pragma unroll
-  for (int i = 0; i < MI / 2; ++i) finish_row(i, q1a[i]);
-#pragma unroll
-  for (int i = 0; i < MI / 2; ++i) finish_row(MI / 2 + i, q1b[i]);
+  }
+  if (dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MDM_STAMP(5);
+  }
 }
 
 }  // namespace
+
+int debug_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? MDM_OK : MDM_ERR_LAUNCH;
+}
 
 int g_bf16_variant = 0;  // tuning knob (mdm_set_gemm_variant): 0 = default
 
