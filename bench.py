@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--cfg-scale", type=float, default=7.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams the step's rows are split over")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,7 +157,7 @@ def main():
                                 model_mean_type=D_.ModelMeanType.EPSILON, model_var_type=D_.ModelVarType.FIXED_SMALL,
                                 loss_type=D_.LossType.MSE)
     kw = {"xf_proj": xf_proj.to(dev), "xf_out": xf_out.to(dev), "length": length.to(dev), "text": ["synthetic"] * B}
-    r = diff._runner(m, (B, T, 263), kw, dev, "cfg", a.cfg_scale, 0.0, False, not a.no_graph)
+    r = diff._runner(m, (B, T, 263), kw, dev, "cfg", a.cfg_scale, 0.0, False, not a.no_graph, a.streams)
     r._prepare()
     if r.use_graph:
         g = torch.cuda.CUDAGraph()
@@ -207,6 +208,10 @@ def main():
         value = steps_per_s * world * (B / 32.0)
         achieved = flop_step / (dt / a.steps)
         moe_dt, moe_flop = moe_block_rate(m, 2 * B, T, a.precision)
+        traffic = None  # HBM-side bytes per step from the committed PMC passes (same workload only)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and (a.config, B, T, a.precision) == ("small", 32, 196, 1):
+            traffic = json.load(open(pmc))["total_bytes_per_step"]
         line = {
             "metric": "denoising-steps/sec (B=32, T=196, 263-d, 8 experts)", "value": round(value, 3),
             "unit": "denoising-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -214,11 +219,13 @@ def main():
             "dtype": "bf16" if a.precision == 1 else "bf16x3(fp32-grade)", "data": "synthetic",
             "config": {"workload": f"configs[1]: model_size={a.config}, num_experts=8, B={B}/GPU, T={T}, "
                                    f"{a.schedule}-step DDPM with CFG {a.cfg_scale} (cond+uncond batched as {2 * B} rows), "
-                                   f"N_text={N}, hipGraph={'on' if r.graph is not None else 'off'}",
+                                   f"N_text={N}, hipGraph={'on' if r.graph is not None else 'off'}, streams={r.nstreams if r.chunks else 1}",
                        "global_batch": B * world, "parallelism": f"batch-shard x{world}, weights replicated"},
             "sample_steps_per_s": round(steps_per_s * B * world, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK[a.precision] / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.precision], 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.precision], 4), "traffic": traffic,
+                         "traffic_note": "fabric bytes per step from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, "
+                                         "profiles/r01_pmc_traffic.json" if traffic else None,
                          "what": "whole step: algorithmic FLOP of 2 forwards / wall time per step",
                          "moe_ffn_block": {"achieved": round(moe_flop / moe_dt / 1e12, 2), "us": round(moe_dt * 1e6, 1),
                                            "frac": round(moe_flop / moe_dt / PEAK[a.precision], 4),

@@ -412,9 +412,9 @@ __global__ __launch_bounds__(1024) void moe_offsets_kernel(const int* __restrict
     tot[g] = ht;
     cursor[g] = 0;
     const int br = g / E, e = g - br * E;
-    if (p.usage[br]) {
-      p.usage[br][e] += ut;
-      p.importance[br][e] += it;
+    if (p.usage[br]) {  // atomics: forwards of different batch chunks may run concurrently on separate streams
+      atomicAdd(&p.usage[br][e], ut);
+      atomicAdd(&p.importance[br][e], it);
     }
   }
   __syncthreads();

@@ -127,8 +127,9 @@ class GaussianDiffusion:
 
     # ---- fused step drivers ----------------------------------------------------------------------------
     def _runner(self, model, shape, model_kwargs, device, mode: str, cfg_scale: float, eta: float, clip: bool,
-                use_graph: bool):
-        return _StepRunner(self, model, tuple(shape), model_kwargs or {}, device, mode, cfg_scale, eta, clip, use_graph)
+                use_graph: bool, streams: int = 0):
+        return _StepRunner(self, model, tuple(shape), model_kwargs or {}, device, mode, cfg_scale, eta, clip, use_graph,
+                           streams)
 
     @torch.no_grad()
     def p_sample_loop_with_cfg(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
@@ -182,8 +183,10 @@ class GaussianDiffusion:
 class _StepRunner:
     """Static buffers + (optionally) one captured hipGraph for a whole denoising step."""
 
-    def __init__(self, diff: GaussianDiffusion, model, shape, kw, device, mode, cfg_scale, eta, clip, use_graph):
+    def __init__(self, diff: GaussianDiffusion, model, shape, kw, device, mode, cfg_scale, eta, clip, use_graph,
+                 streams: int = 0):
         self.d, self.model, self.mode = diff, model, mode
+        self.nstreams = int(streams) if streams else int(getattr(model, "sampler_streams", 1))
         self.cfg_scale, self.eta, self.clip, self.use_graph = float(cfg_scale), float(eta), bool(clip), use_graph
         if device is None:
             device = next(model.parameters()).device
@@ -225,8 +228,24 @@ class _StepRunner:
         self.tab = diff._device_table(self.dev)
         self.graph = None
         # time-embedding chain tabulated per timestep + text half of the gated fusion: once per loop, not per step
-        self.stem = model.stem_cache(diff.num_timesteps, self.xp) if hasattr(model, "stem_cache") and \
-            getattr(model, "ephemeral_mode", "frozen") == "frozen" else None
+        frozen = getattr(model, "ephemeral_mode", "frozen") == "frozen"
+        self.stem = model.stem_cache(diff.num_timesteps, self.xp) if hasattr(model, "stem_cache") and frozen else None
+        # Samples never interact, so the R rows of a step can be cut into independent chunks whose forwards run
+        # CONCURRENTLY on separate HIP streams (forked/joined inside the captured graph): most launches of a forward are
+        # latency-bound, and two chains in flight overlap each other's prologues, DMA round trips and tails.
+        self.chunks = None
+        if self.nstreams > 1 and frozen and hasattr(model, "new_workspace") and self.R % self.nstreams == 0:
+            n = self.R // self.nstreams
+            self.side = [torch.cuda.Stream(device=self.dev) for _ in range(self.nstreams - 1)]
+            self.chunks = []
+            for c in range(self.nstreams):
+                sl = slice(c * n, (c + 1) * n)
+                xo_c = self.xo[sl].contiguous()
+                xp_c = self.xp[sl].contiguous()
+                self.chunks.append(dict(
+                    sl=sl, xp=xp_c, xo=xo_c, len=self.len2[sl].contiguous(),
+                    tc=model.prepare_text(xo_c, private=True), stem=model.stem_cache(diff.num_timesteps, xp_c),
+                    ws=model.new_workspace(n, T, xo_c.shape[1])))
 
     # one step on the current stream: reads self.xx[:B] (x_t), writes x_{t-1} back into it
     def _step(self, use_noise: bool):
@@ -236,7 +255,18 @@ class _StepRunner:
         if self.R == 2 * B:
             self.xx[B:].copy_(x)
         L.check(lib.mdm_fill_i64(C.c_void_p(self.ts.data_ptr()), C.c_int64(self.R), C.c_void_p(self.t_dev.data_ptr()), s))
-        if self.stem is not None:
+        if self.chunks is not None:
+            main = torch.cuda.current_stream()
+            for i, ch in enumerate(self.chunks):
+                st = main if i == 0 else self.side[i - 1]
+                if i > 0:
+                    st.wait_stream(main)  # fork: x_t rows and the timestep vector are ready
+                with torch.cuda.stream(st):
+                    self.model(self.xx[ch["sl"]], self.ts[ch["sl"]], ch["len"], xf_proj=ch["xp"], xf_out=ch["xo"],
+                               out=self.eps[ch["sl"]], stem_cache=ch["stem"], text_cache=ch["tc"], workspace=ch["ws"])
+            for st in self.side:
+                main.wait_stream(st)  # join before the guidance / posterior update
+        elif self.stem is not None:
             self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps, stem_cache=self.stem)
         else:
             self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps)

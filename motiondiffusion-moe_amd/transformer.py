@@ -248,24 +248,33 @@ class MotionTransformer(nn.Module):
             self._text_cache = None
         return self._packed
 
-    def _workspace(self, B: int, T: int, N: int) -> torch.Tensor:
+    def workspace_bytes(self, B: int, T: int, N: int) -> int:
         pm = self.pack()
         need = L.lib().mdm_workspace_bytes(C.byref(pm.model), C.c_int32(B), C.c_int32(T), C.c_int32(N))
         if need < 0:
             raise L.MdmError("unsupported model shape for the HIP path")
+        return int(need)
+
+    def new_workspace(self, B: int, T: int, N: int) -> torch.Tensor:
+        """A private scratch buffer (concurrent forwards on different streams must not share one)."""
+        return torch.empty(self.workspace_bytes(B, T, N), dtype=torch.uint8, device=self.device)
+
+    def _workspace(self, B: int, T: int, N: int) -> torch.Tensor:
+        need = self.workspace_bytes(B, T, N)
         if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def prepare_text(self, xf_out: torch.Tensor):
-        """Build (or fetch) the text-side cache for this xf_out [B,N,Dt]."""
+    def prepare_text(self, xf_out: torch.Tensor, private: bool = False):
+        """Build (or fetch) the text-side cache for this xf_out [B,N,Dt].  ``private=True`` returns a cache object
+        owned by the caller (pass it back as ``forward(..., text_cache=)``) instead of the module's single slot."""
         pm = self.pack()
         xf_out = xf_out.detach().to(torch.float32).contiguous()
         B, N, Dt = xf_out.shape
         if Dt != self.text_latent_dim:
             raise ValueError(f"xf_out last dim {Dt} != text_latent_dim {self.text_latent_dim}")
         key = (xf_out.data_ptr(), xf_out._version, B, N, self.precision)
-        if self._text_cache is not None and self._text_cache["key"] == key:
+        if not private and self._text_cache is not None and self._text_cache["key"] == key:
             return self._text_cache
         D, H, L2 = self.latent_dim, self.num_heads, 2 * self.num_layers
         dh = D // H
@@ -279,8 +288,10 @@ class MotionTransformer(nn.Module):
         L.check(L.lib().mdm_text_cache_build(C.byref(pm.model), C.c_void_p(xf_out.data_ptr()), C.byref(tc),
                                              C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
                                              C.c_void_p(L.stream_ptr())), "mdm_text_cache_build")
-        self._text_cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out), "B": B, "N": N}
-        return self._text_cache
+        cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out), "B": B, "N": N, "pm": pm}
+        if not private:
+            self._text_cache = cache
+        return cache
 
     def stem_cache(self, steps: int, xf_proj: torch.Tensor):
         """Per-loop stem cache (include/mdm_hip.h: MdmStemCache): the time-embedding chain tabulated for every integer
@@ -308,7 +319,8 @@ class MotionTransformer(nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor, timesteps: torch.Tensor, length: torch.Tensor,
                 text: Optional[List[str]] = None, xf_proj=None, xf_out=None, *, forced_routing=None,
-                trace: bool = False, out: Optional[torch.Tensor] = None, stem_cache=None):
+                trace: bool = False, out: Optional[torch.Tensor] = None, stem_cache=None, text_cache=None,
+                workspace: Optional[torch.Tensor] = None):
         if not x.is_cuda:
             raise L.MdmError("MotionTransformer.forward needs GPU tensors: the denoiser runs on HIP kernels only")
         B, T, Fe = x.shape
@@ -324,7 +336,7 @@ class MotionTransformer(nn.Module):
         if self.ephemeral_mode == "resample":
             self.draw_ephemerals()
         pm = self.pack()
-        tcache = self.prepare_text(xf_out)
+        tcache = text_cache if text_cache is not None and text_cache.get("pm") is pm else self.prepare_text(xf_out)
         if tcache["B"] != B:
             raise ValueError("xf_out batch does not match x")
         dev = x.device
@@ -332,7 +344,9 @@ class MotionTransformer(nn.Module):
         ts = timesteps.detach().to(device=dev, dtype=torch.int64).contiguous()
         ln = length.detach().to(device=dev, dtype=torch.int32).contiguous()
         xp = xf_proj.detach().to(device=dev, dtype=torch.float32).contiguous()
-        ws = self._workspace(B, T, tcache["N"])
+        ws = workspace if workspace is not None else self._workspace(B, T, tcache["N"])
+        if ws.numel() < self.workspace_bytes(B, T, tcache["N"]):
+            raise ValueError("workspace too small for this (B, T, N)")
         if out is None:
             out = torch.empty((B, T, Fe), dtype=torch.float32, device=dev)
         fr = forced_routing.to(device=dev, dtype=torch.int32).contiguous() if forced_routing is not None else None
