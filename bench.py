@@ -51,33 +51,43 @@ def build_model(cfg_name, device, precision, B, T, N, seed=0):
     return m, (x, length, xf_proj, xf_out), host
 
 
-def cpu_baseline(host, inputs, steps_total, cfg_scale):
-    """The oracle (CPU restatement, pinned to the reference by golden vectors) timed on this host: one CFG step."""
+def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=16):
+    """The oracle (CPU restatement, pinned to the reference by golden vectors) timed on this host: one CFG step
+    (2 forwards) on a bounded sample of the batch, scaled linearly to the full batch (samples are independent)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import denoiser_ref as R
     import diffusion_ref as DR
     x, length, xf_proj, xf_out = inputs
     B = x.shape[0]
-    cores = os.cpu_count() or 1
+    n = min(sample_rows, B)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    xo_u = host["xo_u"].expand(B, -1, -1).contiguous()
+    print(f"[bench] cpu_baseline: timing the oracle on {n}/{B} samples with {cores} threads ...", file=sys.stderr, flush=True)
+    xo_u = host["xo_u"].expand(n, -1, -1).contiguous()
     xp_u = xo_u.mean(1)
     tb = DR.Tables(DR.linear_betas(steps_total))
     t = steps_total - 1
-    tt = torch.full((B,), t, dtype=torch.int64)
+    tt = torch.full((n,), t, dtype=torch.int64)
+    xs, ls = x[:n], length[:n]
 
-    def fwd(xx, cond, rows=B):
-        xp, xo = (xf_proj, xf_out) if cond else (xp_u, xo_u)
-        return R.denoiser_forward(host["sd"], host["mcfg"], xx[:rows], tt[:rows], length[:rows], xp[:rows], xo[:rows],
+    def fwd(cond, rows=n):
+        xp, xo = (xf_proj[:n], xf_out[:n]) if cond else (xp_u, xo_u)
+        return R.denoiser_forward(host["sd"], host["mcfg"], xs[:rows], tt[:rows], ls[:rows], xp[:rows], xo[:rows],
                                   host["eph"], host["proj"])
 
     with torch.no_grad():
-        fwd(x, True, rows=2)  # page in weights / warm the thread pool
+        fwd(True, rows=1)  # page in weights / warm the thread pool
         t0 = time.perf_counter()
-        DR.cfg_step(tb, t, x, fwd(x, True), fwd(x, False), torch.zeros_like(x), cfg_scale)
+        DR.cfg_step(tb, t, xs, fwd(True), fwd(False), torch.zeros_like(xs), cfg_scale)
         dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
-            "sample": f"1 CFG step (2 forwards, B={B}, T={x.shape[1]}) of the torch-CPU oracle, fp32, {dt:.1f} s"}
+    full = dt * B / n
+    print(f"[bench] cpu_baseline: {dt:.1f} s for the sample -> {full:.1f} s per full step", file=sys.stderr, flush=True)
+    return {"value": 1.0 / full, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+            "sample": f"1 CFG step (2 forwards) of the torch-CPU oracle (fp32) on {n} of the {B} samples, T={x.shape[1]}, "
+                      f"{dt:.1f} s measured, scaled x{B / n:g} to the batch"}
 
 
 def time_block(fn, iters=20):
