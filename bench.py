@@ -51,6 +51,31 @@ def build_model(cfg_name, device, precision, B, T, N, seed=0):
     return m, (x, length, xf_proj, xf_out), host
 
 
+def usable_cores() -> int:
+    """Threads the CPU leg may really use: the cgroup CPU quota when there is one (a GPU box exposes every host core in
+    the affinity mask but schedules only its share), else the affinity mask, never more than 16 (the documented
+    per-GPU CPU share of the pool); MDM_CPU_THREADS overrides."""
+    if os.environ.get("MDM_CPU_THREADS"):
+        return max(1, int(os.environ["MDM_CPU_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=16):
     """The oracle (CPU restatement, pinned to the reference by golden vectors) timed on this host: one CFG step
     (2 forwards) on a bounded sample of the batch, scaled linearly to the full batch (samples are independent)."""
@@ -60,10 +85,7 @@ def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=16):
     x, length, xf_proj, xf_out = inputs
     B = x.shape[0]
     n = min(sample_rows, B)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     print(f"[bench] cpu_baseline: timing the oracle on {n}/{B} samples with {cores} threads ...", file=sys.stderr, flush=True)
     xo_u = host["xo_u"].expand(n, -1, -1).contiguous()
