@@ -76,7 +76,7 @@ def usable_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=16):
+def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=32, nsteps=3):
     """The oracle (CPU restatement, pinned to the reference by golden vectors) timed on this host: one CFG step
     (2 forwards) on a bounded sample of the batch, scaled linearly to the full batch (samples are independent)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -95,7 +95,8 @@ def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=16):
     tt = torch.full((n,), t, dtype=torch.int64)
     xs, ls = x[:n], length[:n]
 
-    def fwd(cond, rows=n):
+    def fwd(cond, rows=None):
+        rows = n if rows is None else rows
         xp, xo = (xf_proj[:n], xf_out[:n]) if cond else (xp_u, xo_u)
         return R.denoiser_forward(host["sd"], host["mcfg"], xs[:rows], tt[:rows], ls[:rows], xp[:rows], xo[:rows],
                                   host["eph"], host["proj"])
@@ -103,13 +104,15 @@ def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=16):
     with torch.no_grad():
         fwd(True, rows=1)  # page in weights / warm the thread pool
         t0 = time.perf_counter()
-        DR.cfg_step(tb, t, xs, fwd(True), fwd(False), torch.zeros_like(xs), cfg_scale)
-        dt = time.perf_counter() - t0
+        for i in range(nsteps):
+            xs, _ = DR.cfg_step(tb, t, xs, fwd(True), fwd(False), torch.zeros_like(xs), cfg_scale)
+            print(f"[bench] cpu_baseline: step {i + 1}/{nsteps} done at {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        dt = (time.perf_counter() - t0) / nsteps
     full = dt * B / n
     print(f"[bench] cpu_baseline: {dt:.1f} s for the sample -> {full:.1f} s per full step", file=sys.stderr, flush=True)
     return {"value": 1.0 / full, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
-            "sample": f"1 CFG step (2 forwards) of the torch-CPU oracle (fp32) on {n} of the {B} samples, T={x.shape[1]}, "
-                      f"{dt:.1f} s measured, scaled x{B / n:g} to the batch"}
+            "sample": f"{nsteps} CFG steps (2 forwards each) of the torch-CPU oracle (fp32) on {n} of the {B} samples, "
+                      f"T={x.shape[1]}, {dt:.1f} s per step measured" + (f", scaled x{B / n:g} to the batch" if n != B else "")}
 
 
 def time_block(fn, iters=20):

@@ -38,7 +38,7 @@ int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const f
 int head_softmax(float* q, int64_t units, int dh, hipStream_t s);
 // fused Performer attention core (perf_attn.hip): qkv fp32 (M,3D) -> LN_dh(num/den) as bf16 (M,D)
 bool perf_attn_supported(int dh, int S);
-int perf_attn(const float* qkv, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
+int perf_attn(const void* qkv, int qkv_bf16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s);
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
 // fused text cross-attention cores (xattn.hip), head_dim 128

@@ -146,15 +146,16 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H, mf = dh;  // m = min(dh, 256) = dh for dh <= 256
   const Work& w = c.w;
-  // q|k|v = 0.1 * (xn W^T + b)                                   (:145-157)
+  const bool fused = c.bf && perf_attn_supported(dh, c.S);
+  // q|k|v = 0.1 * (xn W^T + b)                                   (:145-157); bf16 when the fused attention core reads it
   {
     LinOpts o;
     o.alpha = 0.1f;
-    MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, w.qkv, nullptr, o));
+    MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, fused ? nullptr : w.qkv, fused ? (uint16_t*)w.qkv : nullptr, o));
   }
-  if (c.bf && perf_attn_supported(dh, c.S)) {
+  if (fused) {
     // throughput mode: LN/L2 -> feature maps -> KV state -> num/den -> LN in ONE kernel per (batch, head)  (:44-90)
-    MDM_TRY(perf_attn(w.qkv, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, (uint16_t*)w.t4, c.s));
+    MDM_TRY(perf_attn(w.qkv, 1, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, (uint16_t*)w.t4, c.s));
   } else {
     // shared LN over head_dim, L2 normalise q,k                     (:44-55)
     MDM_TRY(head_norm(w.qkv, c.M, H, dh, p.hn_w, p.hn_b, c.s));

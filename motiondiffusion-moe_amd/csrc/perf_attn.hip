@@ -33,7 +33,8 @@ __device__ __forceinline__ float quad_sum(float v) {  // across the 4 lanes that
   return v;
 }
 
-__global__ __launch_bounds__(256, 1) void perf_attn_kernel(const float* __restrict__ qkv, const uint16_t* __restrict__ PT,
+template <bool QKV16>  // qkv stored as bf16 (written by the QKV GEMM epilogue) or fp32
+__global__ __launch_bounds__(256, 1) void perf_attn_kernel(const void* __restrict__ qkv_, const uint16_t* __restrict__ PT,
                                                            int ldp, const float* __restrict__ hn_w,
                                                            const float* __restrict__ hn_b, const int* __restrict__ len,
                                                            int S, int H, uint16_t* __restrict__ out) {
@@ -74,12 +75,25 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const float* __restri
   auto load_norm = [&](int which, int t0, bool l2, float (&x)[32]) {
     const int t = t0 + r16;
     const int tc = t < S ? t : S - 1;
-    const float* p = qkv + ((int64_t)(b * S + tc)) * 3 * D + which * D + h * DH + 8 * q;
+    const int64_t off = ((int64_t)(b * S + tc)) * 3 * D + which * D + h * DH + 8 * q;
+    if constexpr (QKV16) {
+      const uint16_t* p = (const uint16_t*)qkv_ + off;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 u = *(const uint4*)(p + 32 * ks);
+        x[8 * ks + 0] = bf16_lo_f32(u.x), x[8 * ks + 1] = bf16_hi_f32(u.x);
+        x[8 * ks + 2] = bf16_lo_f32(u.y), x[8 * ks + 3] = bf16_hi_f32(u.y);
+        x[8 * ks + 4] = bf16_lo_f32(u.z), x[8 * ks + 5] = bf16_hi_f32(u.z);
+        x[8 * ks + 6] = bf16_lo_f32(u.w), x[8 * ks + 7] = bf16_hi_f32(u.w);
+      }
+    } else {
+      const float* p = (const float*)qkv_ + off;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
+      }
     }
     float s = 0.f;
 #pragma unroll
@@ -271,20 +285,24 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const float* __restri
 
 bool perf_attn_supported(int dh, int S) { return dh == DH && S >= 1 && S <= 224; }
 
-int perf_attn(const float* qkv, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
+int perf_attn(const void* qkv, int qkv_bf16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s) {
   if (!perf_attn_supported(dh, S)) return MDM_ERR_UNSUPPORTED;
   if (!qkv || !PT || !hn_w || !hn_b || !len || !out || (ldp & 7)) return MDM_ERR_ARG;
   const int TP = (S + 31) & ~31, TS = TP + 8;
   const int vreg = (DH * TS > MF * PS) ? DH * TS : MF * PS;
   const int smem = (MF * TS + vreg + DH * PS) * 2;
-  static int attr = 0;
-  if (smem > attr) {
-    if (hipFuncSetAttribute((const void*)perf_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-      return MDM_ERR_LAUNCH;
-    attr = smem;
+  static int attr[2] = {0, 0};
+  const void* fn = qkv_bf16 ? (const void*)perf_attn_kernel<true> : (const void*)perf_attn_kernel<false>;
+  if (smem > attr[qkv_bf16 ? 1 : 0]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return MDM_ERR_LAUNCH;
+    attr[qkv_bf16 ? 1 : 0] = smem;
   }
-  hipLaunchKernelGGL(perf_attn_kernel, dim3(B * H), dim3(256), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
+  if (qkv_bf16) {
+    hipLaunchKernelGGL(perf_attn_kernel<true>, dim3(B * H), dim3(256), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
+  } else {
+    hipLaunchKernelGGL(perf_attn_kernel<false>, dim3(B * H), dim3(256), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
+  }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

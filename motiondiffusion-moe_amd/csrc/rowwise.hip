@@ -115,14 +115,23 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
                                                        const float* w1, const float* b1, void* y1, int y1_bf,
                                                        const float* w2, const float* b2, void* y2, int y2_bf) {
   const int lane = threadIdx.x & 63;
-  for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
-    Row<NE, VEC> r;
+  // two rows per wave per iteration: both rows' loads are in flight before either is reduced
+  for (int64_t row = 2 * (blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6)); row < M; row += 2 * (int64_t)gridDim.x * WPB) {
+    const bool two = row + 1 < M;
+    Row<NE, VEC> r, q;
     r.load(x + row * D, D, lane);
+    q.load(x + (two ? row + 1 : row) * D, D, lane);
     r.layernorm(w1, b1, D, lane);
-    if (y1) r.store_as(y1, row, D, lane, y1_bf);
+    q.layernorm(w1, b1, D, lane);
+    if (y1) {
+      r.store_as(y1, row, D, lane, y1_bf);
+      if (two) q.store_as(y1, row + 1, D, lane, y1_bf);
+    }
     if (w2) {
       r.layernorm(w2, b2, D, lane);
+      q.layernorm(w2, b2, D, lane);
       r.store_as(y2, row, D, lane, y2_bf);
+      if (two) q.store_as(y2, row + 1, D, lane, y2_bf);
     }
   }
 }
@@ -726,7 +735,7 @@ int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1,
   if (M <= 0) return MDM_OK;
   if (!x || !w1 || !b1 || (w2 && (!b2 || !y2)) || (!w2 && !y1)) return MDM_ERR_ARG;
 #define CALL(NE, VEC) \
-  hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, w1, b1, y1, y1_bf, w2, b2, y2, y2_bf)
+  hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid((M + 1) / 2)), dim3(256), 0, s, x, M, D, w1, b1, y1, y1_bf, w2, b2, y2, y2_bf)
   MDM_ROW_DISPATCH(D, CALL);
 #undef CALL
   MDM_RETURN_IF_LAUNCH_FAILED();
