@@ -28,7 +28,7 @@ struct MoeGateParams {
 int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, void* y1, int y1_bf, const float* w2,
              const float* b2, void* y2, int y2_bf, hipStream_t s);
 int style_in(const float* x, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw,
-             const float* sb, const float* sc, const int* pos4, void* out, int out_bf, hipStream_t s);
+             const float* sb, const float* sc, const int* pos4, int x_bf, void* out, int out_bf, hipStream_t s);
 int to_bf16(const float* src, int64_t n, uint16_t* dst, hipStream_t s);
 int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, int* goff, int* cursor, int* perm,
               float* rowscale, int* pos4, hipStream_t s);
@@ -43,9 +43,9 @@ int perf_attn(const void* qkv, int qkv_bf16, const uint16_t* PT, int ldp, const 
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
 // fused text cross-attention cores (xattn.hip), head_dim 128
 bool xattn_supported(int dh, int N);
-int sd_attn(const float* q, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
+int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
             float* out32, hipStream_t s);
-int lin_xattn(const float* ql, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s);
+int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s);
 int col_softmax(float* k, int B, int N, int D, hipStream_t s);
 int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s);
 int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s);

@@ -133,9 +133,9 @@ int linear_to_act(const Ctx& c, Act A, int64_t M, int K, const MdmPacked& W, con
 // out = resid + out_scale * colscale * Lin(SiLU(LN(a)(1+scale)+shift)) with a = [post-processed] src
 int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float* pw, const float* pb, const int* pos4,
                 const float* sc, float* tmp, const float* resid, float out_scale, const float* colscale, float* out,
-                uint16_t* out16 = nullptr) {
+                uint16_t* out16 = nullptr, bool src_bf16 = false) {
   const int D = c.m->D;
-  MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, tmp, c.bf, c.s));
+  MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, src_bf16, tmp, c.bf, c.s));
   LinOpts o;
   o.out_scale = out_scale, o.R1 = resid, o.colscale = colscale;
   return linear(c, act_of(c, tmp), c.M, D, st.out, st.out_b, D, out, out16, o);
@@ -236,9 +236,10 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
   const int D = m.D, H = m.H, dh = D / H;
   const Work& w = c.w;
   MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, c.bf, nullptr, nullptr, nullptr, 0, c.s));
-  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, w.t3, nullptr));
-  if (c.bf && xattn_supported(dh, 1)) {
-    MDM_TRY(lin_xattn(w.t3, at, c.B, c.S, H, dh, w.t4, c.s));  // softmax over head_dim + q A, fused (:248,253)
+  const bool fused = c.bf && xattn_supported(dh, 1);
+  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
+  if (fused) {
+    MDM_TRY(lin_xattn(w.t3, 1, at, c.B, c.S, H, dh, w.t4, c.s));  // softmax over head_dim + q A, fused (:248,253)
   } else {
     MDM_TRY(head_softmax(w.t3, c.M * H, dh, c.s));  // softmax over head_dim (:248)
     {
@@ -300,11 +301,11 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     g.M = (int)(4 * c.M), g.N = D, g.K = F;
     g.bias = l.b2, g.bias_bs = D;
     g.rowscale = w.rowscale;
-    g.C = w.y2, g.ldc = D;
+    g.C = w.y2, g.ldc = D;  // fp32: the four routed rows of a token are summed in the stylization kernel
     MDM_TRY(gemm(g, c.s));
   }
   // mean of the two branches (each the sum of its two routed rows), stylization, residual
-  return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16);
+  return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, false);
 }
 
 // MemoryEfficientCrossAttentionBlock (fast_attention.py:301-330); out must not alias x
@@ -316,10 +317,12 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
   {
     LinOpts o;
     o.alpha = 1.f / sqrtf((float)dh);
-    MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.sd_q, l.sd_q_b, D, w.t1, nullptr, o));
+    const bool fz = c.bf && xattn_supported(dh, N);
+    MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.sd_q, l.sd_q_b, D, fz ? nullptr : w.t1,
+                   fz ? (uint16_t*)w.t1 : nullptr, o));
   }
   if (c.bf && xattn_supported(dh, N)) {
-    MDM_TRY(sd_attn(w.t1, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.s));  // scores, softmax, PV fused
+    MDM_TRY(sd_attn(w.t1, 1, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.s));  // scores, softmax, PV fused
   } else {
     {
       GemmArgs g = gemm_defaults(c.prec);  // scores[b,h,s,n] = q . k

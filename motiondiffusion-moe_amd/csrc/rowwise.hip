@@ -28,6 +28,22 @@ struct Row {
       }
     }
   }
+  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ p, int D, int lane) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c) {
+        const uint2 u = *(const uint2*)(p + 4 * (lane + 64 * c));
+        e[4 * c + 0] = bf16_lo_f32(u.x), e[4 * c + 1] = bf16_hi_f32(u.x);
+        e[4 * c + 2] = bf16_lo_f32(u.y), e[4 * c + 3] = bf16_hi_f32(u.y);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int i = lane + 64 * j;
+        e[j] = i < D ? __uint_as_float(((uint32_t)p[i]) << 16) : 0.f;
+      }
+    }
+  }
   __device__ __forceinline__ void store(float* __restrict__ p, int D, int lane) const {
     if constexpr (VEC) {
 #pragma unroll
@@ -146,16 +162,25 @@ __global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__
                                                        const float* sw, const float* sb,  // style norm
                                                        const float* __restrict__ sc,      // (B, 2D) scale|shift
                                                        const int* __restrict__ pos4,      // optional (M,4) rows of y2
+                                                       int x_bf,                           // y2 rows are bf16
                                                        void* __restrict__ out, int out_bf) {
   const int lane = threadIdx.x & 63;
   for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
     Row<NE, VEC> r;
     if (pos4) {
       Row<NE, VEC> a, b, c, d;
-      a.load(x + (int64_t)pos4[row * 4 + 0] * D, D, lane);
-      b.load(x + (int64_t)pos4[row * 4 + 1] * D, D, lane);
-      c.load(x + (int64_t)pos4[row * 4 + 2] * D, D, lane);
-      d.load(x + (int64_t)pos4[row * 4 + 3] * D, D, lane);
+      if (x_bf) {
+        const uint16_t* xh = (const uint16_t*)x;
+        a.load_bf16(xh + (int64_t)pos4[row * 4 + 0] * D, D, lane);
+        b.load_bf16(xh + (int64_t)pos4[row * 4 + 1] * D, D, lane);
+        c.load_bf16(xh + (int64_t)pos4[row * 4 + 2] * D, D, lane);
+        d.load_bf16(xh + (int64_t)pos4[row * 4 + 3] * D, D, lane);
+      } else {
+        a.load(x + (int64_t)pos4[row * 4 + 0] * D, D, lane);
+        b.load(x + (int64_t)pos4[row * 4 + 1] * D, D, lane);
+        c.load(x + (int64_t)pos4[row * 4 + 2] * D, D, lane);
+        d.load(x + (int64_t)pos4[row * 4 + 3] * D, D, lane);
+      }
 #pragma unroll
       for (int j = 0; j < NE; ++j) r.e[j] = ((a.e[j] + b.e[j]) + (c.e[j] + d.e[j])) * 0.5f;
     } else {
@@ -743,12 +768,12 @@ int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1,
 }
 
 int style_in(const float* x, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw,
-             const float* sb, const float* sc, const int* pos4, void* out, int out_bf, hipStream_t s) {
+             const float* sb, const float* sc, const int* pos4, int x_bf, void* out, int out_bf, hipStream_t s) {
   if (M <= 0) return MDM_OK;
   if (!x || !sw || !sb || !sc || !out || S <= 0) return MDM_ERR_ARG;
 #define CALL(NE, VEC)                                                                                              \
   hipLaunchKernelGGL((style_in_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, S, pw, pb, sw, sb, sc, \
-                     pos4, out, out_bf)
+                     pos4, x_bf, out, out_bf)
   MDM_ROW_DISPATCH(D, CALL);
 #undef CALL
   MDM_RETURN_IF_LAUNCH_FAILED();

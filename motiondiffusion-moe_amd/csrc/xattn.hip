@@ -28,19 +28,32 @@ __device__ __forceinline__ float quad_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
-// row (t0 + lane&15) of a (M, D) fp32 matrix, head h: x[32] at k = 32*ks + 8*q + j
-__device__ __forceinline__ void load_row(const float* __restrict__ base, int64_t row, int D, int h, int q, float (&x)[32]) {
-  const float* p = base + row * D + h * DH + 8 * q;
+// row (t0 + lane&15) of a (M, D) fp32 / bf16 matrix, head h: x[32] at k = 32*ks + 8*q + j
+template <bool IN16>
+__device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t row, int D, int h, int q, float (&x)[32]) {
+  if constexpr (IN16) {
+    const uint16_t* p = (const uint16_t*)base + row * D + h * DH + 8 * q;
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint4 u = *(const uint4*)(p + 32 * ks);
+      x[8 * ks + 0] = bf16_lo_f32(u.x), x[8 * ks + 1] = bf16_hi_f32(u.x);
+      x[8 * ks + 2] = bf16_lo_f32(u.y), x[8 * ks + 3] = bf16_hi_f32(u.y);
+      x[8 * ks + 4] = bf16_lo_f32(u.z), x[8 * ks + 5] = bf16_hi_f32(u.z);
+      x[8 * ks + 6] = bf16_lo_f32(u.w), x[8 * ks + 7] = bf16_hi_f32(u.w);
+    }
+  } else {
+    const float* p = (const float*)base + row * D + h * DH + 8 * q;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
+    }
   }
 }
 
-template <int NT32>  // ceil(N / 32)
-__global__ __launch_bounds__(256) void sd_attn_kernel(const float* __restrict__ qm, const float* __restrict__ kc,
+template <int NT32, bool IN16>  // ceil(N / 32); q stored as bf16 or fp32
+__global__ __launch_bounds__(256) void sd_attn_kernel(const void* __restrict__ qm, const float* __restrict__ kc,
                                                       const float* __restrict__ vc, int S, int H, int N,
                                                       uint16_t* __restrict__ out16, float* __restrict__ out32) {
   __shared__ __attribute__((aligned(16))) uint16_t kL[NT32 * 32 * PS];  // k [n][d]
@@ -63,7 +76,7 @@ __global__ __launch_bounds__(256) void sd_attn_kernel(const float* __restrict__ 
   for (int tile = wid; tile < ntile; tile += 4) {
     const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
     float x[32];
-    load_row(qm, (int64_t)b * S + tc, D, h, q, x);
+    load_row<IN16>(qm, (int64_t)b * S + tc, D, h, q, x);
     frag_t qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag(x + 8 * ks);
@@ -124,7 +137,8 @@ __global__ __launch_bounds__(256) void sd_attn_kernel(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void lin_xattn_kernel(const float* __restrict__ ql, const float* __restrict__ at, int S,
+template <bool IN16>
+__global__ __launch_bounds__(256) void lin_xattn_kernel(const void* __restrict__ ql, const float* __restrict__ at, int S,
                                                         int H, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint16_t aL[DH * PS];  // A^T [l][d]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
@@ -140,7 +154,7 @@ __global__ __launch_bounds__(256) void lin_xattn_kernel(const float* __restrict_
   for (int tile = wid; tile < ntile; tile += 4) {
     const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
     float x[32];
-    load_row(ql, (int64_t)b * S + tc, D, h, q, x);
+    load_row<IN16>(ql, (int64_t)b * S + tc, D, h, q, x);
     float mx = -INFINITY;  // softmax over head_dim (:248)
 #pragma unroll
     for (int i = 0; i < 32; ++i) mx = fmaxf(mx, x[i]);
@@ -179,26 +193,32 @@ __global__ __launch_bounds__(256) void lin_xattn_kernel(const float* __restrict_
 
 bool xattn_supported(int dh, int N) { return dh == DH && N >= 1 && N <= NP; }
 
-int sd_attn(const float* q, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
+int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
             float* out32, hipStream_t s) {
   if (!xattn_supported(dh, N)) return MDM_ERR_UNSUPPORTED;
   if (!q || !kc || !vc || (!out16 && !out32)) return MDM_ERR_ARG;
   const dim3 grid(B * H), block(256);
+#define MDM_SD(NT, I16) hipLaunchKernelGGL((sd_attn_kernel<NT, I16>), grid, block, 0, s, q, kc, vc, S, H, N, out16, out32)
   if (N <= 32) {
-    hipLaunchKernelGGL(sd_attn_kernel<1>, grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);
+    if (q_bf16) MDM_SD(1, true); else MDM_SD(1, false);
   } else if (N <= 64) {
-    hipLaunchKernelGGL(sd_attn_kernel<2>, grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);
+    if (q_bf16) MDM_SD(2, true); else MDM_SD(2, false);
   } else {
-    hipLaunchKernelGGL(sd_attn_kernel<3>, grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);
+    if (q_bf16) MDM_SD(3, true); else MDM_SD(3, false);
   }
+#undef MDM_SD
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
 
-int lin_xattn(const float* ql, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s) {
+int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s) {
   if (dh != DH) return MDM_ERR_UNSUPPORTED;
   if (!ql || !at || !out) return MDM_ERR_ARG;
-  hipLaunchKernelGGL(lin_xattn_kernel, dim3(B * H), dim3(256), 0, s, ql, at, S, H, out);
+  if (ql_bf16) {
+    hipLaunchKernelGGL(lin_xattn_kernel<true>, dim3(B * H), dim3(256), 0, s, ql, at, S, H, out);
+  } else {
+    hipLaunchKernelGGL(lin_xattn_kernel<false>, dim3(B * H), dim3(256), 0, s, ql, at, S, H, out);
+  }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
