@@ -56,6 +56,10 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 // exact (erf) GELU, nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// exp on the hardware exp2 unit (v_exp_f32): ~1e-6 relative error for |x| <= 15, 2 instructions instead of ~25.
+// Used only where the result is rounded to bf16 right after (throughput-mode attention cores).
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 

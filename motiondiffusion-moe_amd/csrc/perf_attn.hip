@@ -33,8 +33,7 @@ __device__ __forceinline__ float quad_sum(float v) {  // across the 4 lanes that
   return v;
 }
 
-template <bool QKV16>  // qkv stored as bf16 (written by the QKV GEMM epilogue) or fp32
-__global__ __launch_bounds__(256, 1) void perf_attn_kernel(const void* __restrict__ qkv_, const uint16_t* __restrict__ PT,
+__global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ PT,
                                                            int ldp, const float* __restrict__ hn_w,
                                                            const float* __restrict__ hn_b, const int* __restrict__ len,
                                                            int S, int H, uint16_t* __restrict__ out) {
@@ -65,35 +64,40 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const void* __restric
     }
   }
 
-  auto load_PT = [&]() {
-    for (int i = tid; i < MF * 16; i += 256) {
-      const int row = i >> 4, c = i & 15;
-      *(uint4*)(PTl + row * PS + c * 8) = *(const uint4*)(PT + (int64_t)row * ldp + c * 8);
+  auto load_PT = [&]() {  // 128 x 128 bf16 = 2048 16-B chunks, 8 per thread: all loads in flight, then the LDS writes
+    uint4 tmp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + 256 * k;
+      tmp[k] = *(const uint4*)(PT + (int64_t)(i >> 4) * ldp + (i & 15) * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + 256 * k;
+      *(uint4*)(PTl + (i >> 4) * PS + (i & 15) * 8) = tmp[k];
     }
   };
-  // row t0 + r16 of q (0) / k (1) / v (2): LN over head_dim (+ L2 normalise) -> x[32] at k = 32*ks + 8*q + j
-  auto load_norm = [&](int which, int t0, bool l2, float (&x)[32]) {
-    const int t = t0 + r16;
+  // A wave owns tiles wid, wid+4, ... (<= 4 of them: S <= 224).  All of its k and v rows are requested up front and
+  // its q rows as soon as the k registers are free: one global round trip per phase instead of one per tile.
+  constexpr int MAXT = 4;
+  struct Raw { uint4 u[4]; };  // row t0 + r16, elements k = 32*ks + 8*q + j, bf16
+  auto raw_load = [&](int which, int tile) {
+    Raw r;
+    const int t = tile * 16 + r16;
     const int tc = t < S ? t : S - 1;
-    const int64_t off = ((int64_t)(b * S + tc)) * 3 * D + which * D + h * DH + 8 * q;
-    if constexpr (QKV16) {
-      const uint16_t* p = (const uint16_t*)qkv_ + off;
+    const uint16_t* p = qkv + ((int64_t)(b * S + tc)) * 3 * D + which * D + h * DH + 8 * q;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const uint4 u = *(const uint4*)(p + 32 * ks);
-        x[8 * ks + 0] = bf16_lo_f32(u.x), x[8 * ks + 1] = bf16_hi_f32(u.x);
-        x[8 * ks + 2] = bf16_lo_f32(u.y), x[8 * ks + 3] = bf16_hi_f32(u.y);
-        x[8 * ks + 4] = bf16_lo_f32(u.z), x[8 * ks + 5] = bf16_hi_f32(u.z);
-        x[8 * ks + 6] = bf16_lo_f32(u.w), x[8 * ks + 7] = bf16_hi_f32(u.w);
-      }
-    } else {
-      const float* p = (const float*)qkv_ + off;
+    for (int ks = 0; ks < 4; ++ks) r.u[ks] = *(const uint4*)(p + 32 * ks);
+    return r;
+  };
+  // LN over head_dim (+ L2 normalise) -> x[32]
+  auto normalize = [&](const Raw& r, bool l2, float (&x)[32]) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
-      }
+    for (int ks = 0; ks < 4; ++ks) {
+      x[8 * ks + 0] = bf16_lo_f32(r.u[ks].x), x[8 * ks + 1] = bf16_hi_f32(r.u[ks].x);
+      x[8 * ks + 2] = bf16_lo_f32(r.u[ks].y), x[8 * ks + 3] = bf16_hi_f32(r.u[ks].y);
+      x[8 * ks + 4] = bf16_lo_f32(r.u[ks].z), x[8 * ks + 5] = bf16_hi_f32(r.u[ks].z);
+      x[8 * ks + 6] = bf16_lo_f32(r.u[ks].w), x[8 * ks + 7] = bf16_hi_f32(r.u[ks].w);
     }
     float s = 0.f;
 #pragma unroll
@@ -117,15 +121,27 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const void* __restric
       for (int i = 0; i < 32; ++i) x[i] *= inv;
     }
   };
+  Raw kq[MAXT], vr[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int tile = wid + 4 * i;
+    if (tile < ntile) {
+      kq[i] = raw_load(1, tile);
+      vr[i] = raw_load(2, tile);
+    }
+  }
 
   load_PT();
   __syncthreads();
 
   // ---- K: kphi^T[m][t] ---------------------------------------------------------------------------
-  for (int tile = wid; tile < ntile; tile += 4) {
+#pragma unroll
+  for (int it = 0; it < MAXT; ++it) {
+    const int tile = wid + 4 * it;
+    if (tile >= ntile) break;
     const int t0 = tile * 16;
     float x[32];
-    load_norm(1, t0, true, x);
+    normalize(kq[it], true, x);
     frag_t a[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) a[ks] = make_frag(x + 8 * ks);
@@ -145,18 +161,24 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const void* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int t = t0 + 4 * q + r;
-        v[r] = t < nvalid ? 0.1f * expf(fminf(fmaxf(acc[mt][r], -15.f), 15.f)) : 0.f;  // key mask (:69-74)
+        v[r] = t < nvalid ? 0.1f * exp_fast(fminf(fmaxf(acc[mt][r], -15.f), 15.f)) : 0.f;  // key mask (:69-74)
       }
       *(uint2*)(kT + (16 * mt + r16) * TS + t0 + 4 * q) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
     }
   }
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i)  // k registers are free: request the q rows now, they land during the V / KV phases
+    if (wid + 4 * i < ntile) kq[i] = raw_load(0, wid + 4 * i);
   __syncthreads();  // kphi^T complete, P^T reads done
 
   // ---- V: v^T[d][t] ------------------------------------------------------------------------------
-  for (int tile = wid; tile < ntile; tile += 4) {
+#pragma unroll
+  for (int it = 0; it < MAXT; ++it) {
+    const int tile = wid + 4 * it;
+    if (tile >= ntile) break;
     const int t0 = tile * 16, t = t0 + r16;
     float x[32];
-    load_norm(2, t0, false, x);
+    normalize(vr[it], false, x);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -203,10 +225,13 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const void* __restric
   __syncthreads();
 
   // ---- Q: features -> denominator -> num = qphi KV -> LN -> out -------------------------------------
-  for (int tile = wid; tile < ntile; tile += 4) {
+#pragma unroll
+  for (int it = 0; it < MAXT; ++it) {
+    const int tile = wid + 4 * it;
+    if (tile >= ntile) break;
     const int t0 = tile * 16, t = t0 + r16;
     float x[32];
-    load_norm(0, t0, true, x);
+    normalize(kq[it], true, x);
     frag_t qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag(x + 8 * ks);
@@ -226,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const void* __restric
     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float f = 0.1f * expf(fminf(fmaxf(accf[mt][r], -15.f), 15.f));
+        const float f = 0.1f * exp_fast(fminf(fmaxf(accf[mt][r], -15.f), 15.f));
         accf[mt][r] = f;
         den += f * bf16_bits_to_f32(kT[(16 * mt + 4 * q + r) * TS + t]);  // same-t dot (:81)
       }
@@ -287,22 +312,18 @@ bool perf_attn_supported(int dh, int S) { return dh == DH && S >= 1 && S <= 224;
 
 int perf_attn(const void* qkv, int qkv_bf16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s) {
-  if (!perf_attn_supported(dh, S)) return MDM_ERR_UNSUPPORTED;
+  if (!perf_attn_supported(dh, S) || !qkv_bf16) return MDM_ERR_UNSUPPORTED;
   if (!qkv || !PT || !hn_w || !hn_b || !len || !out || (ldp & 7)) return MDM_ERR_ARG;
   const int TP = (S + 31) & ~31, TS = TP + 8;
   const int vreg = (DH * TS > MF * PS) ? DH * TS : MF * PS;
   const int smem = (MF * TS + vreg + DH * PS) * 2;
-  static int attr[2] = {0, 0};
-  const void* fn = qkv_bf16 ? (const void*)perf_attn_kernel<true> : (const void*)perf_attn_kernel<false>;
-  if (smem > attr[qkv_bf16 ? 1 : 0]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return MDM_ERR_LAUNCH;
-    attr[qkv_bf16 ? 1 : 0] = smem;
+  static int attr = 0;
+  if (smem > attr) {
+    if (hipFuncSetAttribute((const void*)perf_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return MDM_ERR_LAUNCH;
+    attr = smem;
   }
-  if (qkv_bf16) {
-    hipLaunchKernelGGL(perf_attn_kernel<true>, dim3(B * H), dim3(256), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
-  } else {
-    hipLaunchKernelGGL(perf_attn_kernel<false>, dim3(B * H), dim3(256), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
-  }
+  hipLaunchKernelGGL(perf_attn_kernel, dim3(B * H), dim3(256), smem, s, (const uint16_t*)qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

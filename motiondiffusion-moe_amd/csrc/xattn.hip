@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void sd_attn_kernel(const void* __restrict__ q
     for (int nt = 0; nt < 2 * NT32; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sc[nt][r] = expf(sc[nt][r] - mx);
+        sc[nt][r] = exp_fast(sc[nt][r] - mx);
         sum += sc[nt][r];
       }
     const float inv = 1.f / quad_sum(sum);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void lin_xattn_kernel(const void* __restrict__
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-      x[i] = expf(x[i] - mx);
+      x[i] = exp_fast(x[i] - mx);
       sum += x[i];
     }
     const float inv = 1.f / quad_sum(sum);
