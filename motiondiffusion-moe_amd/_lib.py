@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdm_hip.so")
+LIB_PATH = os.environ.get("MDM_LIB") or os.path.join(_HERE, "libmdm_hip.so")  # MDM_LIB: A/B benchmarking of builds
 _lib = None
 
 OP_F32_ROW, OP_F32_KSTRIDE, OP_BF16_ROW = 0, 1, 2

@@ -17,8 +17,8 @@ struct MoeGateParams {
   int hn_bf16;
   int* top_idx;            // (2, M, 2)
   float* top_val;          // (2, M, 2)
-  int* hist;               // [512][32] per-block partial histograms (no atomics, no memset)
-  float* uimp;             // [512][64] per-block partial usage | importance increments
+  int* hist;               // [1024][32] per-block partial histograms (no atomics, no memset)
+  float* uimp;             // [1024][64] per-block partial usage | importance increments
   float* usage[2];         // optional persistent counters (E) each (switch_moe.py:71-92)
   float* importance[2];
   const int* forced_idx;   // optional (2, M, 2) injected routing (tests)

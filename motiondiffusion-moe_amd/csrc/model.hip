@@ -59,7 +59,7 @@ Work carve(const MdmModel& m, int B, int T, int N, void* ws) {
   w.y2 = b.take<float>(4 * M * D);
   w.top_idx = b.take<int>(4 * M), w.top_val = b.take<float>(4 * M);
   w.perm = b.take<int>(4 * M), w.rowscale = b.take<float>(4 * M), w.pos4 = b.take<int>(4 * M);
-  w.hist = b.take<int>(512 * 32), w.uimp = b.take<float>(512 * 64), w.goff = b.take<int>(2 * m.E + 1), w.cursor = b.take<int>(2 * m.E);
+  w.hist = b.take<int>(1024 * 32), w.uimp = b.take<float>(1024 * 64), w.goff = b.take<int>(2 * m.E + 1), w.cursor = b.take<int>(2 * m.E);
   w.len_low = b.take<int>(B);
   const int64_t smax = Te > 2 * D ? Te : 2 * D;
   w.s_a = b.take<float>(B * smax), w.s_b = b.take<float>(B * smax), w.s_c = b.take<float>(B * smax);

@@ -356,46 +356,42 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
             logit[e] += h[0] * g[0] + h[1] * g[1] + h[2] * g[2] + h[3] * g[3];
           }
       }
-      float mx = -INFINITY;
+      // top-2 is decided on the LOGITS (softmax is monotone; ties -> lowest index), the softmax denominator is built
+      // with one exp per lane (lane e owns expert e) instead of E exps in every lane
+      float mx = -INFINITY, mine = -INFINITY;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         if (e < E) {
           logit[e] = group_sum<16>(logit[e]) + p.gate_b[br][e];
           mx = fmaxf(mx, logit[e]);
+          mine = (l16 == e) ? logit[e] : mine;
         }
       }
-      float den = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        logit[e] = e < E ? expf(logit[e] - mx) : 0.f;
-        den += logit[e];
-      }
+      const float den = group_sum<16>(l16 < E ? expf(mine - mx) : 0.f);
       int i1 = 0, i2 = -1;
-      float v1 = -1.f, v2 = -1.f;
+      float l1 = -INFINITY, l2 = -INFINITY;
       if (p.forced_idx) {
         i1 = p.forced_idx[((int64_t)br * M + rc) * 2 + 0];
         i2 = p.forced_idx[((int64_t)br * M + rc) * 2 + 1];
-        v1 = v2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float pe = logit[e] / den;
-          v1 = e == i1 ? pe : v1;
-          v2 = e == i2 ? pe : v2;
+          l1 = e == i1 ? logit[e] : l1;
+          l2 = e == i2 ? logit[e] : l2;
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float pe = logit[e] / den;
           if (e < E) {
-            if (pe > v1) {
-              v2 = v1, i2 = i1;
-              v1 = pe, i1 = e;
-            } else if (pe > v2) {
-              v2 = pe, i2 = e;
+            if (logit[e] > l1) {
+              l2 = l1, i2 = i1;
+              l1 = logit[e], i1 = e;
+            } else if (logit[e] > l2) {
+              l2 = logit[e], i2 = e;
             }
           }
         }
       }
+      const float v1 = expf(l1 - mx) / den, v2 = expf(l2 - mx) / den;
       if (ok && l16 == 0) {
         const int64_t o = ((int64_t)br * M + row) * 2;
         p.top_idx[o] = i1, p.top_idx[o + 1] = i2;
@@ -788,7 +784,7 @@ int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, i
   if (D % 64 == 0 && D <= 1024) {
     const int smem = 2 * E * D * 4 + 3 * 32 * 4;
     int64_t nb = (M + 15) / 16;
-    const int grid = (int)(nb > 512 ? 512 : nb);
+    const int grid = (int)(nb > 512 ? 512 : nb);  // measured end to end: 256 blocks -2 %, 1024 blocks -0.5 %
     nparts = grid;
     static int attr_done = 0;
     if (smem > 65536 && smem > attr_done) {
