@@ -50,5 +50,7 @@ inline Operand op_bf16(const uint16_t* hi, const uint16_t* lo, int64_t ld) {
 int gemm(const GemmArgs& a, hipStream_t stream);
 bool gemm_bf16_eligible(const GemmArgs& a);
 int gemm_bf16(const GemmArgs& a, hipStream_t stream);  // gemm2.hip: bf16 x bf16 throughput kernel
+bool gemm_bf16_256_eligible(const GemmArgs& a);
+int gemm_bf16_256(const GemmArgs& a, hipStream_t stream);  // gemm4.hip: 256x256 tile, 8 waves
 
 }  // namespace mdm

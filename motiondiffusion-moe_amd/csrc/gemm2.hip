@@ -302,6 +302,7 @@ int debug_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? MDM_OK : MDM_ERR_LAUNCH;
 }
 
+int g_big_min_tiles = 352;
 int g_bf16_variant = 0;  // tuning knob (mdm_set_gemm_variant): 0 = default
 
 bool gemm_bf16_eligible(const GemmArgs& a) {
@@ -342,6 +343,13 @@ static int launch_bf16(const GemmArgs& a, hipStream_t stream) {
 int gemm_bf16(const GemmArgs& a, hipStream_t stream) {
   if (!gemm_bf16_eligible(a)) return MDM_ERR_UNSUPPORTED;
   if (!a.C && !a.C16) return MDM_ERR_ARG;
+  // long-K, many-tile launches: 256x256 tiles halve the L2->LDS bytes per FLOP (1090 vs 865 TFLOP/s at 8192^3), but
+  // with one workgroup per CU their prologue / 4-slab epilogue is not hidden: measured slower than the 128^2 tiles at
+  // K = 512 / 1024 (e.g. 50176x1024x512: 142 vs 128 us), so they are used for K >= 2048 only (variant 6 forces, 7 forbids)
+  if (g_bf16_variant != 7 && g_bf16_variant != 1 && g_bf16_variant != 2 && gemm_bf16_256_eligible(a)) {
+    const int64_t t256 = (int64_t)((a.M + 255) / 256 + (a.goff ? a.ngroups : 0)) * (a.N / 256);
+    if (g_bf16_variant == 6 || (a.K >= 2048 && t256 >= g_big_min_tiles)) return gemm_bf16_256(a, stream);
+  }
   // few 128x128 tiles => the launch is a latency chain on <= 2 blocks per CU: halve the tile height so that every
   // CU holds 3+ independent blocks (variant 1 / 2 force the 128- / 64-row tile for benchmarking)
   const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + BN - 1) / BN) * a.batch;

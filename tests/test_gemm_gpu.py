@@ -220,3 +220,62 @@ def test_bf16_kernel_grouped_gather():
         r = slice(int(off[e]), int(off[e + 1]))
         ref[r] = torch.nn.functional.gelu(x.cpu().double()[gather[r].long()] @ wb[e].T + b[e].cpu().double())
     assert rel_inf(out.cpu(), ref.float()) < 1e-4
+
+
+@pytest.fixture
+def force_256():
+    L, _ = _mods()
+    L.lib().mdm_set_gemm_variant(6)  # force the 256x256-tile kernel (gemm4.hip) where eligible
+    yield
+    L.lib().mdm_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(512, 256, 64, 0), (12544, 512, 512, 1), (700, 768, 128, 2), (255, 1024, 192, 0)])
+def test_bf16_256_tile_kernel(force_256, M, N, K, act):
+    L, ops = _mods()
+    x, w, b = _rand(M, K, seed=41), _rand(N, K, seed=42), _rand(N, seed=43)
+    xb = x.to(torch.bfloat16)
+    pw = ops.PackedWeight(w)
+    r1, r2, cs, rs = _rand(M, N, seed=44), _rand(M, N, seed=45), _rand(N, seed=46), _rand(M, seed=47)
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    y = ops.linear(xb, pw, b, act=act, alpha=0.9, out_scale=0.5, colscale=cs, rowscale=rs, r1=r1, r1_scale=0.3, r2=r2,
+                   precision=1, out16=out16)
+    fn = {0: lambda v: v, 1: torch.nn.functional.gelu, 2: torch.nn.functional.silu}[act]
+    ref = fn(0.9 * (xb.double() @ w.to(torch.bfloat16).double().T + b.double())) * 0.5
+    ref = ref * cs.double()[None] * rs.double()[:, None] + 0.3 * r1.double() + r2.double()
+    assert rel_inf(y.cpu(), ref.float().cpu()) < 1e-4
+    assert torch.equal(out16, y.to(torch.bfloat16))
+
+
+def test_bf16_256_tile_grouped_gather(force_256):
+    L, ops = _mods()
+    E, D, F_, Mtok = 5, 128, 256, 900
+    x = _rand(Mtok, D, seed=51).to(torch.bfloat16)
+    w, b = _rand(E, F_, D, seed=52), _rand(E, F_, seed=53)
+    counts = torch.tensor([0, 300, 1, 513, 256])
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = counts.cumsum(0)
+    tot = int(off[-1])
+    gather = torch.randint(0, Mtok, (tot,), generator=torch.Generator().manual_seed(3), dtype=torch.int32)
+    pw = ops.PackedWeight(w)
+    out = torch.zeros(tot, F_, device="cuda")
+    rs = _rand(tot, seed=54)
+    d = ops.gemm_desc(1)
+    gd, od = gather.cuda(), off.cuda()
+    d.A.p, d.A.ld, d.A.kind, d.A.gather = x.data_ptr(), D, L.OP_BF16_ROW, gd.data_ptr()
+    d.W = pw.operand()
+    d.W.bs1 = F_ * pw.Kp
+    d.goff, d.ngroups = od.data_ptr(), E
+    d.M, d.N, d.K = tot, F_, D
+    d.bias, d.bias_bs = b.data_ptr(), F_
+    d.rowscale = rs.data_ptr()
+    d.C, d.ldc = out.data_ptr(), F_
+    d.act = L.ACT_GELU
+    ops.run_gemm(d)
+    ref = torch.empty(tot, F_, dtype=torch.float64)
+    wb = w.to(torch.bfloat16).cpu().double()
+    for e in range(E):
+        r = slice(int(off[e]), int(off[e + 1]))
+        ref[r] = torch.nn.functional.gelu(x.cpu().double()[gather[r].long()] @ wb[e].T + b[e].cpu().double())
+    ref = ref * rs.cpu().double()[:, None]
+    assert rel_inf(out.cpu(), ref.float()) < 1e-4
