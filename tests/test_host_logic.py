@@ -118,3 +118,19 @@ def test_trainer_surface():
     assert tr._model() is m
     with pytest.raises(NotImplementedError):
         tr.train()
+
+
+def test_trainer_checkpoint_roundtrip(tmp_path):
+    """DDPMTrainer.save / load keep the reference's checkpoint dict (ddpm_trainer.py:260-289)."""
+    Tr, T = pkg("trainer"), pkg("transformer")
+    kw = dict(num_frames=8, latent_dim=64, ff_size=64, num_layers=1, num_heads=4, text_latent_dim=32, moe_num_experts=2)
+    m1, m2 = T.MotionTransformer(263, **kw), T.MotionTransformer(263, **kw)
+    args = types.SimpleNamespace(device=torch.device("cpu"), diffusion_steps=50, is_train=False)
+    t1, t2 = Tr.DDPMTrainer(args, m1), Tr.DDPMTrainer(args, m2)
+    f = str(tmp_path / "latest.tar")
+    t1.save(f, ep=3, total_it=77)
+    ck = torch.load(f)
+    assert set(ck) == {"opt_encoder", "ep", "total_it", "encoder"}
+    assert t2.load(f) == (3, 77)
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)

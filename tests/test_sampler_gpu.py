@@ -105,3 +105,35 @@ def test_trainer_generate_api():
     outs = tr.generate(["a", "b", "c"], torch.tensor([16, 12, 16]), 263, batch_size=2)
     assert len(outs) == 3 and all(o.shape == (16, 263) for o in outs)
     assert all(torch.isfinite(o).all() for o in outs)
+
+
+def test_multi_stream_step_matches_single_stream():
+    """--streams: cond / uncond rows run as concurrent forwards on two HIP streams inside the captured step; samples
+    never interact, so the result must equal the single-stream run exactly and the MoE counters must agree."""
+    g, meta, m, diff, noises, kw = _setup()
+    d = diff(meta["steps_cfg"])
+    outs, counters = [], []
+    for streams in (1, 2):
+        m.reset_all_moe_counters()
+        r = d._runner(m, tuple(g["x_T"].shape), kw, "cuda", "cfg", meta["cfg_scale"], 0.0, False, True, streams)
+        outs.append(r.run(g["x_T"].cuda(), noises("cfg", meta["steps_cfg"]), False, None).cpu())
+        counters.append({k: v.clone().cpu() for k, v in m.moe_buffers().items()})
+    assert torch.equal(outs[0], outs[1])
+    for k in counters[0]:
+        assert torch.allclose(counters[0][k], counters[1][k], rtol=1e-5, atol=1e-3), k
+
+
+def test_resample_mode_redraws_projections_like_the_reference():
+    """ephemeral_mode='resample': fresh random emb projections before every forward, drawn from the CPU default
+    generator in the reference's order (stylization.py:22-24) -> seed-reproducible, different across calls."""
+    g, meta = load_golden("fwd_tiny")
+    m, _ = build_module(meta, precision=3)
+    m.ephemeral_mode = "resample"
+    args = (g["x"].cuda(), g["timesteps"].cuda(), g["length"].cuda())
+    kw = dict(xf_proj=g["xf_proj"].cuda(), xf_out=g["xf_out"].cuda())
+    torch.manual_seed(5)
+    a = m(*args, **kw).cpu()
+    b = m(*args, **kw).cpu()
+    torch.manual_seed(5)
+    c = m(*args, **kw).cpu()
+    assert not torch.equal(a, b) and torch.equal(a, c)
