@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams the step's rows are split over")
+    ap.add_argument("--variant", type=int, default=0, help="kernel-selection knob for same-box A/B runs (mdm_set_gemm_variant)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,6 +186,8 @@ def main():
     D_ = importlib.import_module("motiondiffusion-moe_amd.diffusion")
     dmod = importlib.import_module("motiondiffusion-moe_amd.dist")
 
+    if a.variant:
+        importlib.import_module("motiondiffusion-moe_amd._lib").lib().mdm_set_gemm_variant(a.variant)
     B, T, N = a.batch, a.frames, 28
     m, inputs, host = build_model(a.config, dev, a.precision, B, T, N, seed=0)
     x, length, xf_proj, xf_out = inputs

@@ -70,6 +70,40 @@ typedef struct MdmGemmDesc {
 
 int mdm_gemm(const MdmGemmDesc* desc, void* stream);
 
+/* Fused two-layer MLP (throughput mode, bf16 operands, fp32 accumulation):
+ *   Y[m,:] = ( GELU(X[src(m),:] W1^T + b1) W2^T + b2 ) * rowscale[m] + r1_scale * R1[m,:] + R2[m,:]
+ * the hidden activations stay on chip.  Replaces the Linear-GELU-Linear pairs of the path: the expert MLPs
+ * (switch_moe.py:19-25, grouped by goff with per-expert strides w?_gs / b?_gs), the 4x FFN of the text cross-attention
+ * block (fast_attention.py:293-299) and the Performer output projection (fast_attention.py:121-126).
+ * Supported shapes: Dout == 512, Din % 64 == 0, F % 256 == 0; anything else returns MDM_ERR_UNSUPPORTED. */
+typedef struct MdmMlpDesc {
+  const uint16_t* X; /* bf16 rows [*, Din] */
+  int64_t ldx;
+  const int32_t* gather; /* optional: row m reads X[gather[m]] */
+  int32_t M, Din, F, Dout;
+  const int32_t* goff;
+  int32_t ngroups;
+  const uint16_t* w1; /* bf16 [F, Din] (row stride ldw1) */
+  int64_t ldw1, w1_gs;
+  const float* b1;
+  int64_t b1_gs;
+  const uint16_t* w2; /* bf16 [Dout, F] (row stride ldw2) */
+  int64_t ldw2, w2_gs;
+  const float* b2;
+  int64_t b2_gs;
+  const float* rowscale;
+  const float* R1;
+  int64_t ldr1;
+  float r1_scale;
+  const float* R2;
+  int64_t ldr2;
+  float* C;      /* fp32 output (may be NULL when C16 is set) */
+  uint16_t* C16; /* optional bf16 copy */
+  int64_t ldc;
+} MdmMlpDesc;
+
+int mdm_fused_mlp(const MdmMlpDesc* desc, void* stream);
+
 /* fp32 [rows, K] (row stride ld_src) -> bf16 planes [rows, Kpad] (Kpad = ld_dst, multiple of 32, zero padded);
  * lo may be NULL.  Weight packing happens once at load time (not on the hot path). */
 int mdm_pack_bf16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* hi, uint16_t* lo,

@@ -36,6 +36,15 @@ class GemmDesc(C.Structure):
                 ("feat_rpt", C.c_int32), ("feat_kslot", C.c_int32), ("precision", C.c_int32)]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("gather", C.c_void_p), ("M", C.c_int32), ("Din", C.c_int32),
+                ("F", C.c_int32), ("Dout", C.c_int32), ("goff", C.c_void_p), ("ngroups", C.c_int32),
+                ("w1", C.c_void_p), ("ldw1", C.c_int64), ("w1_gs", C.c_int64), ("b1", C.c_void_p), ("b1_gs", C.c_int64),
+                ("w2", C.c_void_p), ("ldw2", C.c_int64), ("w2_gs", C.c_int64), ("b2", C.c_void_p), ("b2_gs", C.c_int64),
+                ("rowscale", C.c_void_p), ("R1", C.c_void_p), ("ldr1", C.c_int64), ("r1_scale", C.c_float),
+                ("R2", C.c_void_p), ("ldr2", C.c_int64), ("C", C.c_void_p), ("C16", C.c_void_p), ("ldc", C.c_int64)]
+
+
 class Packed(C.Structure):
     _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("ld", C.c_int64)]
 
@@ -114,7 +123,7 @@ def lib():
 
 
 # every symbol include/mdm_hip.h declares (checked by tests/test_abi.py)
-EXPORTS = ["mdm_version", "mdm_gemm", "mdm_pack_bf16", "mdm_workspace_bytes", "mdm_text_cache_build",
+EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_pack_bf16", "mdm_workspace_bytes", "mdm_text_cache_build",
            "mdm_denoiser_forward", "mdm_stem_cache_build", "mdm_block_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
            "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant", "mdm_debug_stamps"]
 

@@ -41,6 +41,11 @@ int mdm_gemm(const MdmGemmDesc* d, void* stream) {
   return mdm::gemm(*d, (hipStream_t)stream);
 }
 
+int mdm_fused_mlp(const MdmMlpDesc* d, void* stream) {
+  if (!d) return MDM_ERR_ARG;
+  return mdm::fused_mlp(*d, (hipStream_t)stream);
+}
+
 int mdm_pack_bf16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* hi, uint16_t* lo,
                   int64_t ld_dst, void* stream) {
   if (!src || !hi || rows < 0 || K <= 0 || ld_dst < K || (ld_dst & 31)) return MDM_ERR_ARG;

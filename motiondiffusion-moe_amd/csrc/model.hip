@@ -5,6 +5,7 @@
 #include "kernels.h"
 
 namespace mdm {
+extern int g_bf16_variant;
 namespace {
 
 #define MDM_TRY(expr)            \
@@ -271,6 +272,19 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
   }
   p.hn = w.hn, p.hn_bf16 = c.bf, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.uimp = w.uimp, p.forced_idx = forced;
   MDM_TRY(moe_route(x, c.M, D, E, p, w.goff, w.cursor, w.perm, w.rowscale, w.pos4, c.s));
+  MdmMlpDesc f = {};
+  f.X = (const uint16_t*)w.hn, f.ldx = D, f.gather = w.perm;
+  f.M = (int)(4 * c.M), f.Din = D, f.F = F, f.Dout = D;
+  f.goff = w.goff, f.ngroups = 2 * E;
+  f.w1 = l.w1.hi, f.ldw1 = l.w1.ld, f.w1_gs = (int64_t)F * l.w1.ld, f.b1 = l.b1, f.b1_gs = F;
+  f.w2 = l.w2.hi, f.ldw2 = l.w2.ld, f.w2_gs = (int64_t)D * l.w2.ld, f.b2 = l.b2, f.b2_gs = D;
+  f.rowscale = w.rowscale, f.r1_scale = 1.f;
+  f.C = w.y2, f.ldc = D;
+  if (c.bf && g_bf16_variant != 21 && fused_mlp_supported(f)) {  // variant 21: two-GEMM chain, for A/B runs
+    // throughput mode: both expert GEMMs in one kernel, hidden activations stay in LDS (switch_moe.py:19-25,104-109)
+    MDM_TRY(fused_mlp(f, c.s));
+    return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, false);
+  }
   {
     GemmArgs g = gemm_defaults(c.prec);  // hidden = GELU(LN_b(x)[routed rows] W1_e^T + b1_e)
     if (c.bf) {

@@ -94,3 +94,40 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
         d.R2, d.ldr2 = r2.data_ptr(), r2.stride(0)
     run_gemm(d)
     return out.reshape(*x.shape[:-1], w.N)
+
+
+def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w2: PackedWeight,
+              b2: Optional[torch.Tensor], *, gather=None, goff=None, rowscale=None, r1=None, r1_scale: float = 1.0,
+              r2=None, rows: Optional[int] = None, out: Optional[torch.Tensor] = None,
+              out16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = (GELU(x w1^T + b1) w2^T + b2) * rowscale + r1_scale * r1 + r2 with the hidden layer kept on chip (mlp.hip).
+    ``goff`` (int32 [G+1], device) selects grouped mode: w1 / w2 / b1 / b2 then carry a leading group axis."""
+    L.require_cuda(x16)
+    assert x16.dtype == torch.bfloat16 and x16.stride(-1) == 1
+    x2 = x16.reshape(-1, x16.shape[-1])
+    M = x2.shape[0] if rows is None else rows
+    F, Dout = w1.N, w2.N
+    assert w1.K == x2.shape[1] and w2.K == F
+    if out is None:
+        out = torch.empty((M, Dout), dtype=torch.float32, device=x16.device)
+    d = L.MlpDesc()
+    d.X, d.ldx, d.gather = x2.data_ptr(), x2.stride(0), L.ptr(gather)
+    d.M, d.Din, d.F, d.Dout = M, w1.K, F, Dout
+    if goff is not None:
+        d.goff, d.ngroups = goff.data_ptr(), goff.numel() - 1
+        d.w1_gs, d.w2_gs = F * w1.Kp, Dout * w2.Kp
+        d.b1_gs, d.b2_gs = F, Dout
+    d.w1, d.ldw1, d.b1 = w1.hi.data_ptr(), w1.Kp, L.ptr(b1)
+    d.w2, d.ldw2, d.b2 = w2.hi.data_ptr(), w2.Kp, L.ptr(b2)
+    d.rowscale = L.ptr(rowscale)
+    d.r1_scale = r1_scale
+    if r1 is not None:
+        d.R1, d.ldr1 = r1.data_ptr(), r1.stride(0)
+    if r2 is not None:
+        d.R2, d.ldr2 = r2.data_ptr(), r2.stride(0)
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    if out16 is not None:
+        assert out16.stride(0) == out.stride(0)
+        d.C16 = out16.data_ptr()
+    L.check(L.lib().mdm_fused_mlp(C.byref(d), C.c_void_p(L.stream_ptr())), "mdm_fused_mlp")
+    return out

@@ -1,0 +1,79 @@
+"""GPU: the fused Linear-GELU-Linear kernel (csrc/mlp.hip) through the C ABI against a torch fp64 reference that applies
+the same operand rounding (bf16 inputs / weights / hidden activations, wide accumulation)."""
+import pytest
+import torch
+
+from conftest import pkg, rel_inf
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-3  # bf16 hidden-layer rounding flips + fp32 accumulation order; operands are rounded identically in the reference
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return ((torch.rand(*shape, generator=g) * 2 - 1) * scale).cuda()
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).double()
+
+
+def _ref(x16, w1, b1, w2, b2):
+    h = torch.nn.functional.gelu(x16.double() @ _bf(w1).T + b1.double())
+    return _bf(h.float()) @ _bf(w2).T + b2.double()
+
+
+@pytest.mark.parametrize("M,Din,F", [(128, 512, 1024), (300, 512, 2048), (77, 128, 256), (1, 64, 512), (1000, 512, 512)])
+def test_dense(M, Din, F):
+    ops = pkg("ops")
+    Dout = 512
+    x16 = _rand(M, Din, seed=1).to(torch.bfloat16)
+    w1, b1 = _rand(F, Din, seed=2, scale=Din ** -0.5), _rand(F, seed=3, scale=0.1)
+    w2, b2 = _rand(Dout, F, seed=4, scale=F ** -0.5), _rand(Dout, seed=5, scale=0.1)
+    r1, r2 = _rand(M, Dout, seed=6), _rand(M, Dout, seed=7)
+    pw1, pw2 = ops.PackedWeight(w1, with_lo=False), ops.PackedWeight(w2, with_lo=False)
+    y16 = torch.zeros(M, Dout, dtype=torch.bfloat16, device="cuda")
+    y = ops.fused_mlp(x16, pw1, b1, pw2, b2, r1=r1, r1_scale=0.5, r2=r2, out16=y16)
+    ref = (_ref(x16, w1, b1, w2, b2) + 0.5 * r1.double() + r2.double()).float()
+    assert rel_inf(y.cpu(), ref.cpu()) < TOL
+    assert rel_inf(y16.float().cpu(), ref.cpu()) < 1e-2
+    plain = ops.fused_mlp(x16, pw1, None, pw2, None)
+    z = torch.zeros(1, device="cuda")
+    ref0 = _ref(x16, w1, z.expand(F), w2, z.expand(Dout)).float()
+    assert rel_inf(plain.cpu(), ref0.cpu()) < TOL
+
+
+def test_grouped_gathered_ragged():
+    """Expert layout: rows sorted by group with ragged (and one empty) group sizes, gathered source rows, row scale."""
+    ops = pkg("ops")
+    Din, F, Dout, G, S = 512, 1024, 512, 5, 400
+    sizes = [130, 0, 257, 1, 128]
+    M = sum(sizes)
+    goff = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
+    src = _rand(S, Din, seed=11).to(torch.bfloat16)
+    g = torch.Generator(device="cpu").manual_seed(12)
+    gather = torch.randint(0, S, (M,), generator=g, dtype=torch.int32).cuda()
+    w1, b1 = _rand(G, F, Din, seed=13, scale=Din ** -0.5), _rand(G, F, seed=14, scale=0.1)
+    w2, b2 = _rand(G, Dout, F, seed=15, scale=F ** -0.5), _rand(G, Dout, seed=16, scale=0.1)
+    rs = _rand(M, seed=17).abs()
+    pw1, pw2 = ops.PackedWeight(w1, with_lo=False), ops.PackedWeight(w2, with_lo=False)
+    out = torch.full((M + 3, Dout), 7.0, device="cuda")
+    ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out=out)
+    x = src[gather.long()]
+    ref = torch.empty(M, Dout, dtype=torch.float64, device="cuda")
+    o = 0
+    for e, n in enumerate(sizes):
+        ref[o:o + n] = _ref(x[o:o + n], w1[e], b1[e], w2[e], b2[e]) * rs[o:o + n, None].double()
+        o += n
+    assert rel_inf(out[:M].cpu(), ref.float().cpu()) < TOL
+    assert torch.all(out[M:] == 7.0)  # rows past the last group are untouched
+
+
+def test_unsupported_shapes_are_refused():
+    L, ops = pkg("_lib"), pkg("ops")
+    x16 = _rand(8, 80, seed=1).to(torch.bfloat16)
+    pw1 = ops.PackedWeight(_rand(256, 80, seed=2), with_lo=False)
+    pw2 = ops.PackedWeight(_rand(512, 256, seed=3), with_lo=False)
+    with pytest.raises(L.MdmError):
+        ops.fused_mlp(x16, pw1, None, pw2, None)  # Din % 64 != 0
