@@ -157,6 +157,29 @@ def moe_block_rate(m, B2, T, precision):
     return dt, flop
 
 
+def expert_mlp_rate(m, B2, T):
+    """HIP-event timing of the dominant kernel alone (fused expert MLP, csrc/mlp.hip) at the step's shape: 4*M routed
+    rows (2 branches x top-2) spread evenly over 2*E expert slabs, gathered from 2*M normalised rows.  Algorithmic FLOP
+    per launch = 4 * rows * D * F (two GEMMs).  Returns (seconds, flop) or None when the shape is not covered."""
+    ops = importlib.import_module("motiondiffusion-moe_amd.ops")
+    D, F_, E = m.latent_dim, m.ff_size, m.moe_num_experts
+    if D != 512 or F_ % 256 or m.precision != 1:
+        return None
+    dev, M = m.device, B2 * T
+    rows, G = 4 * M, 2 * E
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x16 = torch.randn(2 * M, D, generator=g).to(dev).to(torch.bfloat16)
+    w1 = ops.PackedWeight((torch.randn(G, F_, D, generator=g) * D ** -0.5).to(dev), with_lo=False)
+    w2 = ops.PackedWeight((torch.randn(G, D, F_, generator=g) * F_ ** -0.5).to(dev), with_lo=False)
+    b1, b2 = torch.zeros(G, F_, device=dev), torch.zeros(G, D, device=dev)
+    gather = torch.randint(0, 2 * M, (rows,), generator=g, dtype=torch.int32).to(dev)
+    goff = (torch.arange(G + 1, dtype=torch.int64) * rows // G).to(torch.int32).to(dev)
+    rs = torch.rand(rows, generator=g).to(dev)
+    out = torch.empty(rows, D, device=dev)
+    dt = time_block(lambda: ops.fused_mlp(x16, w1, b1, w2, b2, gather=gather, goff=goff, rowscale=rs, rows=rows, out=out))
+    return dt, 4.0 * rows * D * F_
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +269,7 @@ def main():
         value = steps_per_s * world * (B / 32.0)
         achieved = flop_step / (dt / a.steps)
         moe_dt, moe_flop = moe_block_rate(m, 2 * B, T, a.precision)
+        dom = expert_mlp_rate(m, 2 * B, T)
         traffic = None  # HBM-side bytes per step from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc) and (a.config, B, T, a.precision) == ("small", 32, 196, 1):
@@ -255,7 +279,7 @@ def main():
             "unit": "denoising-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.precision == 1 else "bf16x3(fp32-grade)", "data": "synthetic",
-            "config": {"workload": f"configs[1]: model_size={a.config}, num_experts=8, B={B}/GPU, T={T}, "
+            "config": {"workload": f"{'configs[1]' if a.config == 'small' else 'configs[2]'}: model_size={a.config}, num_experts=8, B={B}/GPU, T={T}, "
                                    f"{a.schedule}-step DDPM with CFG {a.cfg_scale} (cond+uncond batched as {2 * B} rows), "
                                    f"N_text={N}, hipGraph={'on' if r.graph is not None else 'off'}, streams={r.nstreams if r.chunks else 1}",
                        "global_batch": B * world, "parallelism": f"batch-shard x{world}, weights replicated"},
@@ -269,6 +293,11 @@ def main():
                                            "frac": round(moe_flop / moe_dt / PEAK[a.precision], 4),
                                            "rows": 2 * B * T, "timed_with": "HIP events on the launch stream"}},
         }
+        if dom is not None:
+            line["roofline"]["dominant_kernel"] = {
+                "name": "fused_mlp_kernel (expert W1-GELU-W2, csrc/mlp.hip)", "achieved": round(dom[1] / dom[0] / 1e12, 2),
+                "us": round(dom[0] * 1e6, 1), "frac": round(dom[1] / dom[0] / PEAK[a.precision], 4),
+                "flop_per_launch": dom[1], "timed_with": "HIP events on the launch stream, kernel alone"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host, inputs, a.schedule, a.cfg_scale)
         print(json.dumps(line), flush=True)
