@@ -213,7 +213,10 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
 }
 
 // DualSelfAttentionBlock (fast_attention.py:208-226): x -> out.  Uses t1..t5.  x16: bf16 shadow of x (throughput mode)
-int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* x16, const float* sc4, float* out) {
+// next_w / next_b: optional LayerNorm of the FOLLOWING block (cross_attn.base_ca.norm) chained onto post_norm; its output
+// goes to t2 typed like the mode, and cross_block(pre_normed = true) picks it up (one launch less per layer)
+int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* x16, const float* sc4, float* out,
+               const float* next_w = nullptr, const float* next_b = nullptr) {
   const int D = c.m->D;
   const Work& w = c.w;
   const int64_t scs = (int64_t)c.B * 2 * D;
@@ -228,15 +231,16 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
     o.act = ACT_GELU, o.R1 = w.t1, o.r1_scale = 0.1f;
     MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.skip, l.skip_b, D, w.t3, nullptr, o));
   }
-  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, 0, nullptr, nullptr, nullptr, 0, c.s);
+  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, 0, next_w, next_b, next_w ? w.t2 : nullptr, c.bf, c.s);
 }
 
 // GatedCrossAttention (fast_attention.py:242-272): out = x + sigmoid(gate)*sigmoid(adaptive)*style(softmax(q) A)
-int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x, const float* sc, float* out) {
+int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x, const float* sc, float* out,
+                bool pre_normed = false) {
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H;
   const Work& w = c.w;
-  MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  if (!pre_normed) MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, c.bf, nullptr, nullptr, nullptr, 0, c.s));
   const bool fused = c.bf && xattn_supported(dh, 1);
   MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
   if (fused) {
@@ -398,9 +402,9 @@ int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, float* x, uin
                ? MDM_OK
                : MDM_ERR_LAUNCH;
   };
-  MDM_TRY(dual_block(c, l, x, x16, sc4, y));
+  MDM_TRY(dual_block(c, l, x, x16, sc4, y, l.ca_norm_w, l.ca_norm_b));
   MDM_TRY(dump(0, y));
-  MDM_TRY(cross_block(c, l, tc_at(m, tc, layer), y, sc4 + 2 * scs, x));
+  MDM_TRY(cross_block(c, l, tc_at(m, tc, layer), y, sc4 + 2 * scs, x, true));
   MDM_TRY(dump(1, x));
   MDM_TRY(moe_block(c, l, x, sc4 + 3 * scs, forced, y, y16));
   MDM_TRY(dump(2, y));
