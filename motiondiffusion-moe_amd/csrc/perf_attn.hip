@@ -1,5 +1,5 @@
 // Fused Performer-style linear attention core (fast_attention.py:29-92) for head_dim = 128, throughput mode.
-// One workgroup (4 waves) per (batch, head); everything between the QKV projection and the output projection
+// One workgroup (8 waves) per (batch, head); everything between the QKV projection and the output projection
 // happens on chip:
 //   K:  k rows -> LN(dh) -> L2 norm -> bf16 A-fragments in registers -> MFMA with P^T (LDS) -> 0.1*exp(clamp) -> mask
 //       -> kphi^T [m][t] in LDS (the accumulator's 4 consecutive t per lane are one 8-byte store)
@@ -15,7 +15,7 @@
 namespace mdm {
 namespace {
 
-constexpr int DH = 128, MF = 128, PS = 136;  // PS: padded row stride (elements) of the 128-wide LDS images
+constexpr int DH = 128, MF = 128, PS = 136, NW = 8, NTH = 64 * NW;  // 8 waves: <= 2 row tiles per wave per phase  // PS: padded row stride (elements) of the 128-wide LDS images
 
 typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -33,7 +33,7 @@ __device__ __forceinline__ float quad_sum(float v) {  // across the 4 lanes that
   return v;
 }
 
-__global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ PT,
+__global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ PT,
                                                            int ldp, const float* __restrict__ hn_w,
                                                            const float* __restrict__ hn_b, const int* __restrict__ len,
                                                            int S, int H, uint16_t* __restrict__ out) {
@@ -64,22 +64,22 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __res
     }
   }
 
-  auto load_PT = [&]() {  // 128 x 128 bf16 = 2048 16-B chunks, 8 per thread: all loads in flight, then the LDS writes
-    uint4 tmp[8];
+  auto load_PT = [&]() {  // 128 x 128 bf16 = 2048 16-B chunks, 4 per thread: all loads in flight, then the LDS writes
+    uint4 tmp[2048 / NTH];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = tid + 256 * k;
+    for (int k = 0; k < 2048 / NTH; ++k) {
+      const int i = tid + NTH * k;
       tmp[k] = *(const uint4*)(PT + (int64_t)(i >> 4) * ldp + (i & 15) * 8);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = tid + 256 * k;
+    for (int k = 0; k < 2048 / NTH; ++k) {
+      const int i = tid + NTH * k;
       *(uint4*)(PTl + (i >> 4) * PS + (i & 15) * 8) = tmp[k];
     }
   };
-  // A wave owns tiles wid, wid+4, ... (<= 4 of them: S <= 224).  All of its k and v rows are requested up front and
+  // A wave owns tiles wid, wid+8 (S <= 224 -> 14 tiles).  All of its k and v rows are requested up front and
   // its q rows as soon as the k registers are free: one global round trip per phase instead of one per tile.
-  constexpr int MAXT = 4;
+  constexpr int MAXT = 2;
   struct Raw { uint4 u[4]; };  // row t0 + r16, elements k = 32*ks + 8*q + j, bf16
   auto raw_load = [&](int which, int tile) {
     Raw r;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __res
   Raw kq[MAXT], vr[MAXT];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
-    const int tile = wid + 4 * i;
+    const int tile = wid + NW * i;
     if (tile < ntile) {
       kq[i] = raw_load(1, tile);
       vr[i] = raw_load(2, tile);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __res
   // ---- K: kphi^T[m][t] ---------------------------------------------------------------------------
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
-    const int tile = wid + 4 * it;
+    const int tile = wid + NW * it;
     if (tile >= ntile) break;
     const int t0 = tile * 16;
     float x[32];
@@ -168,13 +168,13 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __res
   }
 #pragma unroll
   for (int i = 0; i < MAXT; ++i)  // k registers are free: request the q rows now, they land during the V / KV phases
-    if (wid + 4 * i < ntile) kq[i] = raw_load(0, wid + 4 * i);
+    if (wid + NW * i < ntile) kq[i] = raw_load(0, wid + NW * i);
   __syncthreads();  // kphi^T complete, P^T reads done
 
   // ---- V: v^T[d][t] ------------------------------------------------------------------------------
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
-    const int tile = wid + 4 * it;
+    const int tile = wid + NW * it;
     if (tile >= ntile) break;
     const int t0 = tile * 16, t = t0 + r16;
     float x[32];
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __res
         vT[(32 * ks + 8 * q + j) * TS + t] = t < S ? (uint16_t)(pack_bf16(x[8 * ks + j], 0.f) & 0xffff) : (uint16_t)0;
   }
   if (TP > SP) {  // zero the K-padding columns of both images
-    for (int i = tid; i < DH * 16; i += 256) {
+    for (int i = tid; i < DH * 16; i += NTH) {
       const int row = i >> 4, c = i & 15;
       kT[row * TS + SP + c] = 0;
       vT[row * TS + SP + c] = 0;
@@ -196,29 +196,22 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __res
 
   // ---- KV^T[d][m] = 0.1 * sum_t v^T[d][t] kphi^T[m][t]  (:77) ----------------------------------------
   {
-    f32x4 acc[2][8];
+    f32x4 acc[8];  // wave w owns the m tile w (8 waves x 16 = 128 features), all 8 d tiles
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < TP / 32; ++ks) {
-      frag_t a[2], bf[8];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *(const frag_t*)(kT + (16 * (2 * wid + i) + r16) * TS + 32 * ks + 8 * q);
+      frag_t bf[8];
+      const frag_t a = *(const frag_t*)(kT + (16 * wid + r16) * TS + 32 * ks + 8 * q);
 #pragma unroll
       for (int j = 0; j < 8; ++j) bf[j] = *(const frag_t*)(vT + (16 * j + r16) * TS + 32 * ks + 8 * q);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bf[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[j], acc[j], 0, 0, 0);
     }
-    // D[m][d]: col d = 16j + r16, rows m = 16(2w+i) + 4q + r  ->  KV^T[d][m..m+3]
+    // D[m][d]: col d = 16j + r16, rows m = 16w + 4q + r  ->  KV^T[d][m..m+3]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        *(uint2*)(KV + (16 * j + r16) * PS + 16 * (2 * wid + i) + 4 * q) =
-            make_uint2(pack_bf16(0.1f * acc[i][j][0], 0.1f * acc[i][j][1]), pack_bf16(0.1f * acc[i][j][2], 0.1f * acc[i][j][3]));
+    for (int j = 0; j < 8; ++j)
+      *(uint2*)(KV + (16 * j + r16) * PS + 16 * wid + 4 * q) =
+          make_uint2(pack_bf16(0.1f * acc[j][0], 0.1f * acc[j][1]), pack_bf16(0.1f * acc[j][2], 0.1f * acc[j][3]));
   }
   __syncthreads();  // v^T dead: its region takes P^T again
   load_PT();
@@ -227,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void perf_attn_kernel(const uint16_t* __res
   // ---- Q: features -> denominator -> num = qphi KV -> LN -> out -------------------------------------
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
-    const int tile = wid + 4 * it;
+    const int tile = wid + NW * it;
     if (tile >= ntile) break;
     const int t0 = tile * 16, t = t0 + r16;
     float x[32];
@@ -323,7 +316,7 @@ int perf_attn(const void* qkv, int qkv_bf16, const uint16_t* PT, int ldp, const 
       return MDM_ERR_LAUNCH;
     attr = smem;
   }
-  hipLaunchKernelGGL(perf_attn_kernel, dim3(B * H), dim3(256), smem, s, (const uint16_t*)qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
+  hipLaunchKernelGGL(perf_attn_kernel, dim3(B * H), dim3(NTH), smem, s, (const uint16_t*)qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
