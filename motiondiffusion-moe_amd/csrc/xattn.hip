@@ -10,6 +10,7 @@ namespace mdm {
 namespace {
 
 constexpr int DH = 128, PS = 136, NP = 96, NS = NP + 8;  // NS: row stride (elements) of the v^T image
+constexpr int XNT = 512;  // threads per (batch, head) workgroup: 8 waves share the <= 14 row tiles
 
 typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -53,14 +54,14 @@ __device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t 
 }
 
 template <int NT32, bool IN16>  // ceil(N / 32); q stored as bf16 or fp32
-__global__ __launch_bounds__(256) void sd_attn_kernel(const void* __restrict__ qm, const float* __restrict__ kc,
+__global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ qm, const float* __restrict__ kc,
                                                       const float* __restrict__ vc, int S, int H, int N,
                                                       uint16_t* __restrict__ out16, float* __restrict__ out32) {
   __shared__ __attribute__((aligned(16))) uint16_t kL[NT32 * 32 * PS];  // k [n][d]
   __shared__ __attribute__((aligned(16))) uint16_t vT[DH * NS];         // v^T [d][n]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
-  for (int i = tid; i < NT32 * 32 * (DH / 4); i += 256) {
+  for (int i = tid; i < NT32 * 32 * (DH / 4); i += XNT) {
     const int n = i / (DH / 4), c = i - n * (DH / 4);
     f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void sd_attn_kernel(const void* __restrict__ q
   }
   __syncthreads();
   const int ntile = (S + 15) >> 4;
-  for (int tile = wid; tile < ntile; tile += 4) {
+  for (int tile = wid; tile < ntile; tile += XNT / 64) {
     const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
     float x[32];
     load_row<IN16>(qm, (int64_t)b * S + tc, D, h, q, x);
@@ -138,20 +139,20 @@ __global__ __launch_bounds__(256) void sd_attn_kernel(const void* __restrict__ q
 }
 
 template <bool IN16>
-__global__ __launch_bounds__(256) void lin_xattn_kernel(const void* __restrict__ ql, const float* __restrict__ at, int S,
+__global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__ ql, const float* __restrict__ at, int S,
                                                         int H, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint16_t aL[DH * PS];  // A^T [l][d]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
   const float* ab = at + (int64_t)blockIdx.x * DH * DH;
-  for (int i = tid; i < DH * (DH / 4); i += 256) {
+  for (int i = tid; i < DH * (DH / 4); i += XNT) {
     const int l = i / (DH / 4), c = i - l * (DH / 4);
     const f32x4 v = *(const f32x4*)(ab + l * DH + 4 * c);
     *(uint2*)(aL + l * PS + 4 * c) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
   }
   __syncthreads();
   const int ntile = (S + 15) >> 4;
-  for (int tile = wid; tile < ntile; tile += 4) {
+  for (int tile = wid; tile < ntile; tile += XNT / 64) {
     const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
     float x[32];
     load_row<IN16>(ql, (int64_t)b * S + tc, D, h, q, x);
@@ -197,7 +198,7 @@ int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, 
             float* out32, hipStream_t s) {
   if (!xattn_supported(dh, N)) return MDM_ERR_UNSUPPORTED;
   if (!q || !kc || !vc || (!out16 && !out32)) return MDM_ERR_ARG;
-  const dim3 grid(B * H), block(256);
+  const dim3 grid(B * H), block(XNT);
 #define MDM_SD(NT, I16) hipLaunchKernelGGL((sd_attn_kernel<NT, I16>), grid, block, 0, s, q, kc, vc, S, H, N, out16, out32)
   if (N <= 32) {
     if (q_bf16) MDM_SD(1, true); else MDM_SD(1, false);
@@ -215,9 +216,9 @@ int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H,
   if (dh != DH) return MDM_ERR_UNSUPPORTED;
   if (!ql || !at || !out) return MDM_ERR_ARG;
   if (ql_bf16) {
-    hipLaunchKernelGGL(lin_xattn_kernel<true>, dim3(B * H), dim3(256), 0, s, ql, at, S, H, out);
+    hipLaunchKernelGGL(lin_xattn_kernel<true>, dim3(B * H), dim3(XNT), 0, s, ql, at, S, H, out);
   } else {
-    hipLaunchKernelGGL(lin_xattn_kernel<false>, dim3(B * H), dim3(256), 0, s, ql, at, S, H, out);
+    hipLaunchKernelGGL(lin_xattn_kernel<false>, dim3(B * H), dim3(XNT), 0, s, ql, at, S, H, out);
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
