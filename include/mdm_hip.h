@@ -235,6 +235,17 @@ int mdm_ddim_step(const float* x, const float* eps, const float* noise, int64_t 
                   const int32_t* t_dev, int32_t t_imm, float eta, int32_t clip_denoised, float* x_out, float* x0_out,
                   void* stream);
 
+/* Text projection head of the reference's EnhancedTextEncoder (text_encoder.py:13-18,31-43), applied to the
+ * last_hidden_state of any text encoder (the DeBERTa weights themselves are third-party and stay outside this library):
+ *   projected[b] = GELU(Linear(LayerNorm(cat(prompt_tokens, hidden[b]))))   (B, P + N0, Dt) -> xf_out
+ *   pooled[b]    = mean over the P + N0 tokens of projected[b]              (B, Dt)         -> xf_proj
+ * hidden fp32 (B, N0, Hs), prompts fp32 (P, Hs), Hs <= 1024.  ws >= mdm_text_head_workspace_bytes(...). */
+int64_t mdm_text_head_workspace_bytes(int32_t B, int32_t N0, int32_t P, int32_t Hs, int32_t Dt);
+int mdm_text_head_forward(const float* hidden, const float* prompts, const float* ln_w, const float* ln_b,
+                          const MdmPacked* w, const float* bias, int32_t B, int32_t N0, int32_t P, int32_t Hs,
+                          int32_t Dt, float* xf_out, float* xf_proj, void* ws, int64_t ws_bytes, int32_t precision,
+                          void* stream);
+
 /* small helpers used by the host module */
 int mdm_xattn_gate(const float* gate, const float* adaptive_gate, int32_t D, float* out, void* stream);
 int mdm_fill_i64(int64_t* dst, int64_t n, const int32_t* src_dev, void* stream);

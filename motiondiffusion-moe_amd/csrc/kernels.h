@@ -51,6 +51,8 @@ int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s);
 int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s);
 int gated_mix_gather(const float* table, const int64_t* ts, int steps, const float* x, int B, int D, float* out,
                      uint16_t* out16, hipStream_t s);
+int text_assemble(const float* pp, const float* ph, int B, int N0, int P, int Dt, float* xf_out, float* xf_proj,
+                  hipStream_t s);
 int iota_i64(int64_t* dst, int64_t n, int64_t start, hipStream_t s);
 int xattn_gate(const float* gate, const float* ag, int D, float* out, hipStream_t s);
 int halve_lengths(const int* len, int B, int* out, hipStream_t s);

@@ -671,6 +671,45 @@ int mdm_stylization_forward(const MdmStyle* st, const float* h, const float* sc,
   return style_apply(c, *st, h, nullptr, nullptr, nullptr, sc, tmp, nullptr, 1.f, nullptr, out);
 }
 
+int64_t mdm_text_head_workspace_bytes(int32_t B, int32_t N0, int32_t P, int32_t Hs, int32_t Dt) {
+  if (B <= 0 || N0 < 0 || P < 0 || Hs <= 0 || Dt <= 0) return -1;
+  const int64_t fl = (int64_t)B * N0 * Hs + (int64_t)P * Hs + (int64_t)B * N0 * Dt + (int64_t)P * Dt;
+  return ((fl * 4 + 255) & ~(int64_t)255) + 1024;
+}
+
+// EnhancedTextEncoder's projection head (text_encoder.py:13-18,39-43) on the hidden states of any text encoder
+int mdm_text_head_forward(const float* hidden, const float* prompts, const float* ln_w, const float* ln_b,
+                          const MdmPacked* w, const float* bias, int32_t B, int32_t N0, int32_t P, int32_t Hs,
+                          int32_t Dt, float* xf_out, float* xf_proj, void* ws, int64_t ws_bytes, int32_t precision,
+                          void* stream) {
+  if (!ln_w || !ln_b || !w || !w->hi || !xf_out || !xf_proj || !ws || B <= 0 || N0 < 0 || P < 0 || N0 + P <= 0 ||
+      (N0 > 0 && !hidden) || (P > 0 && !prompts))
+    return MDM_ERR_ARG;
+  if (precision != 1 && precision != 3) return MDM_ERR_ARG;
+  if (precision == 3 && !w->lo) return MDM_ERR_ARG;
+  if (ws_bytes < mdm_text_head_workspace_bytes(B, N0, P, Hs, Dt)) return MDM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  Bump b(ws);
+  float* lnh = b.take<float>((int64_t)B * N0 * Hs);
+  float* lnp = b.take<float>((int64_t)P * Hs);
+  float* ph = b.take<float>((int64_t)B * N0 * Dt);
+  float* pp = b.take<float>((int64_t)P * Dt);
+  MdmModel fake = {};
+  Ctx c = {};
+  c.m = &fake, c.s = s, c.prec = precision, c.bf = false;
+  LinOpts o;
+  o.act = ACT_GELU;
+  if (N0 > 0) {
+    MDM_TRY(ln_chain(hidden, (int64_t)B * N0, Hs, ln_w, ln_b, lnh, 0, nullptr, nullptr, nullptr, 0, s));
+    MDM_TRY(linear(c, act_f32(lnh), (int64_t)B * N0, Hs, *w, bias, Dt, ph, nullptr, o));
+  }
+  if (P > 0) {  // the prompt rows are the same for every caption: projected once, broadcast by the assemble kernel
+    MDM_TRY(ln_chain(prompts, P, Hs, ln_w, ln_b, lnp, 0, nullptr, nullptr, nullptr, 0, s));
+    MDM_TRY(linear(c, act_f32(lnp), P, Hs, *w, bias, Dt, pp, nullptr, o));
+  }
+  return text_assemble(pp, ph, B, N0, P, Dt, xf_out, xf_proj, s);
+}
+
 int mdm_cfg_posterior_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n,
                            const float* tab, int32_t steps, const int32_t* t_dev, int32_t t_imm, float cfg_scale,
                            int32_t clip_denoised, float* x_out, float* x0_out, void* stream) {

@@ -646,6 +646,27 @@ __global__ void gated_mix_kernel(const float* __restrict__ t, const float* __res
   out[i] = g * tv + (1.f - g) * xv;
 }
 
+// text_encoder.py:40-43: xf_out[b] = cat(proj(prompts), proj(hidden[b])) ; xf_proj[b] = mean over the P + N0 tokens
+__global__ void text_assemble_kernel(const float* __restrict__ pp, const float* __restrict__ ph, int B, int N0, int P, int Dt,
+                                     float* __restrict__ xf_out, float* __restrict__ xf_proj) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Dt) return;
+  const int b = i / Dt, d = i - b * Dt, N = P + N0;
+  float* o = xf_out + (int64_t)b * N * Dt + d;
+  float s = 0.f;
+  for (int n = 0; n < P; ++n) {
+    const float v = pp[n * Dt + d];
+    o[(int64_t)n * Dt] = v;
+    s += v;
+  }
+  for (int n = 0; n < N0; ++n) {
+    const float v = ph[((int64_t)b * N0 + n) * Dt + d];
+    o[(int64_t)(P + n) * Dt] = v;
+    s += v;
+  }
+  xf_proj[i] = s / (float)N;
+}
+
 // same with t looked up in a per-timestep table (stem cache) and an optional bf16 copy of the result
 __global__ void gated_mix_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ ts, int steps,
                                         const float* __restrict__ x, int B, int D, float* __restrict__ out,
@@ -870,6 +891,13 @@ int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s) {
 
 int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s) {
   hipLaunchKernelGGL(gated_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, x, n, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int text_assemble(const float* pp, const float* ph, int B, int N0, int P, int Dt, float* xf_out, float* xf_proj,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(text_assemble_kernel, dim3((B * Dt + 255) / 256), dim3(256), 0, s, pp, ph, B, N0, P, Dt, xf_out, xf_proj);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

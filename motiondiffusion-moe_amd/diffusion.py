@@ -125,6 +125,102 @@ class GaussianDiffusion:
     def _scale_timesteps(self, t):
         return t
 
+    # ---- elementwise helpers of the reference API (gaussian_diffusion.py:329-341,433-475,554-571) -----------------
+    # Plumbing around the HIP forward: table lookups rounded f64 -> f32 exactly as _extract_into_tensor does, evaluated
+    # with device tensor ops.  The sampling loops do NOT go through these (they use the fused step kernels).
+    def _extract(self, arr: np.ndarray, t: torch.Tensor, shape) -> torch.Tensor:
+        res = torch.from_numpy(np.asarray(arr)).to(t.device)[t.long()].float()
+        while res.dim() < len(shape):
+            res = res[..., None]
+        return res.expand(shape)
+
+    def q_mean_variance(self, x_start, t):
+        mean = self._extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
+        variance = self._extract(1.0 - self.alphas_cumprod, t, x_start.shape)
+        log_variance = self._extract(self.log_one_minus_alphas_cumprod, t, x_start.shape)
+        return mean, variance, log_variance
+
+    def q_sample(self, x_start, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        assert noise.shape == x_start.shape
+        return (self._extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
+                + self._extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        assert x_start.shape == x_t.shape
+        mean = (self._extract(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                + self._extract(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        var = self._extract(self.posterior_variance, t, x_t.shape)
+        logvar = self._extract(self.posterior_log_variance_clipped, t, x_t.shape)
+        return mean, var, logvar
+
+    def _predict_xstart_from_eps(self, x_t, t, eps):
+        assert x_t.shape == eps.shape
+        return (self._extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - self._extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps)
+
+    def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
+        return ((self._extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - pred_xstart)
+                / self._extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape))
+
+    @torch.no_grad()
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """One denoiser forward (HIP) + the epsilon / fixed-variance posterior of gaussian_diffusion.py:481-552.
+        Returns {"mean", "variance", "log_variance", "pred_xstart"}."""
+        self._check_supported(denoised_fn)
+        if model_kwargs is None:
+            model_kwargs = {}
+        B = x.shape[0]
+        assert t.shape == (B,)
+        eps = model(x, self._scale_timesteps(t), **model_kwargs)
+        if self.model_var_type == ModelVarType.FIXED_SMALL:
+            var_tab, logvar_tab = self.posterior_variance, self.posterior_log_variance_clipped
+        elif self.model_var_type == ModelVarType.FIXED_LARGE:
+            var_tab = np.append(self.posterior_variance[1], self.betas[1:])
+            logvar_tab = np.log(var_tab)
+        else:
+            raise NotImplementedError("learned-variance models are out of scope of the HIP sampler")
+        variance = self._extract(var_tab, t, x.shape)
+        log_variance = self._extract(logvar_tab, t, x.shape)
+        pred_xstart = self._predict_xstart_from_eps(x, t, eps)
+        if clip_denoised:
+            pred_xstart = pred_xstart.clamp(-1, 1)
+        mean, _, _ = self.q_posterior_mean_variance(pred_xstart, x, t)
+        assert mean.shape == log_variance.shape == pred_xstart.shape == x.shape
+        return {"mean": mean, "variance": variance, "log_variance": log_variance, "pred_xstart": pred_xstart}
+
+    def _progressive(self, r, noise, step_noise):
+        """Generator form of _StepRunner.run: yields {"sample", "pred_xstart"} after every step (eager launches)."""
+        B = r.B
+        r._prepare()
+        if noise is None:
+            noise = torch.randn((B, r.T, r.Fe), device=r.dev)
+        r.xx[:B].copy_(noise.to(r.dev, torch.float32))
+        r.t_dev.fill_(self.num_timesteps - 1)
+        for i in range(self.num_timesteps):
+            if r._needs_noise():
+                if step_noise is not None:
+                    r.noise.copy_(step_noise[i].to(r.dev, torch.float32))
+                else:
+                    r.noise.normal_()
+            r._step(r._needs_noise())
+            yield {"sample": r.xx[:B].clone(), "pred_xstart": r.x0.clone()}
+
+    @torch.no_grad()
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False, *, step_noise=None):
+        self._check_supported(denoised_fn, cond_fn)
+        r = self._runner(model, shape, model_kwargs, device, "ddpm", 0.0, 0.0, clip_denoised, False)
+        yield from self._progressive(r, noise, step_noise)
+
+    @torch.no_grad()
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, eta=0.0, *, step_noise=None):
+        self._check_supported(denoised_fn, cond_fn)
+        r = self._runner(model, shape, model_kwargs, device, "ddim", 0.0, eta, clip_denoised, False)
+        yield from self._progressive(r, noise, step_noise)
+
     # ---- fused step drivers ----------------------------------------------------------------------------
     def _runner(self, model, shape, model_kwargs, device, mode: str, cfg_scale: float, eta: float, clip: bool,
                 use_graph: bool, streams: int = 0):

@@ -65,7 +65,11 @@ class MotionTransformer(nn.Module):
                 node.register_buffer(parts[-1], torch.zeros(shape))
             else:
                 node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape)))
-        self.text_encoder_fn = text_encoder  # callable(text, device) -> (xf_proj (B,Dt), xf_out (B,N,Dt))
+        # callable(text, device) -> (xf_proj (B,Dt), xf_out (B,N,Dt)); an nn.Module (text_head.EnhancedTextEncoder) is
+        # registered so a reference checkpoint's `text_encoder.*` keys load into it
+        if isinstance(text_encoder, nn.Module):
+            self.text_encoder = text_encoder
+        self.text_encoder_fn = text_encoder
         self._eph: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None
         self._proj: Optional[Dict[str, torch.Tensor]] = None
         self._packed: Optional[PackedModel] = None

@@ -288,6 +288,56 @@ def case_projection_qr():
     print("projection_qr:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def case_text_head():
+    """Runs the reference's EnhancedTextEncoder.forward (text_encoder.py:24-43) with the two network fetches replaced:
+    AutoModel / AutoTokenizer.from_pretrained return tiny deterministic stand-ins, so the reference's own prompt
+    concatenation, projection head and pooling produce the golden outputs."""
+    import types
+    import models.text_encoder as TE
+
+    Hs, Dt, B, N0 = 96, 32, 3, 5
+    hidden = synth.uniform_pm1((B, N0, Hs), "text_head.hidden", 31) * (3.0 ** 0.5)
+
+    class _Bert(nn.Module):
+        config = types.SimpleNamespace(hidden_size=Hs)
+
+        def forward(self, input_ids=None, attention_mask=None, return_dict=True):
+            return types.SimpleNamespace(last_hidden_state=hidden.clone())
+
+    class _Tok:
+        def __call__(self, text, **kw):
+            ids = torch.zeros(len(text), N0, dtype=torch.long)
+            return _Batch(ids)
+
+    class _Batch:
+        def __init__(self, ids):
+            self.input_ids, self.attention_mask = ids, torch.ones_like(ids)
+
+        def to(self, device):
+            return self
+
+    real_m, real_t = TE.AutoModel.from_pretrained, TE.AutoTokenizer.from_pretrained
+    TE.AutoModel.from_pretrained = staticmethod(lambda name: _Bert())
+    TE.AutoTokenizer.from_pretrained = staticmethod(lambda name: _Tok())
+    try:
+        enc = TE.EnhancedTextEncoder(output_dim=Dt).eval()
+    finally:
+        TE.AutoModel.from_pretrained, TE.AutoTokenizer.from_pretrained = real_m, real_t
+    sd = {"proj.0.weight": 1.0 + 0.1 * synth.uniform_pm1((Hs,), "text_head.ln_w", 31),
+          "proj.0.bias": 0.1 * synth.uniform_pm1((Hs,), "text_head.ln_b", 31),
+          "proj.1.weight": synth.uniform_pm1((Dt, Hs), "text_head.w", 31) * Hs ** -0.5,
+          "proj.1.bias": 0.1 * synth.uniform_pm1((Dt,), "text_head.b", 31),
+          "prompt_tokens": synth.uniform_pm1((1, 8, Hs), "text_head.prompts", 31) * (3.0 ** 0.5)}
+    missing = enc.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("bert.") for k in missing.missing_keys), missing
+    with torch.no_grad():
+        pooled, projected = enc(["a person walks"] * B, torch.device("cpu"))
+    out = {"hidden": hidden, "pooled": pooled, "projected": projected}
+    out.update({"sd/" + k: v for k, v in sd.items()})
+    save("text_head", out, {"Hs": Hs, "Dt": Dt, "B": B, "N0": N0, "P": 8, "seed": 31})
+    print("text_head:", tuple(pooled.shape), tuple(projected.shape))
+
+
 def cfgd(D, F_, H, Dt, E, L, size="small", frames=196, feats=263, **extra):
     d = dict(input_feats=feats, num_frames=frames, latent_dim_arg=D, ff_size_arg=F_, num_heads=H,
              text_latent_dim_arg=Dt, moe_num_experts=E, num_layers=L, model_size=size)
@@ -298,7 +348,11 @@ def cfgd(D, F_, H, Dt, E, L, size="small", frames=196, feats=263, **extra):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--text-head-only" in sys.argv:
+        case_text_head()
+        return
     if "--loops-only" not in sys.argv:
+        case_text_head()
         case_layout()
         case_projection_qr()
         case_forward("fwd_tiny", cfgd(64, 128, 4, 32, 4, 1, frames=16), B=2, T=16, N=6, wseed=11, iseed=21)

@@ -134,3 +134,28 @@ def test_trainer_checkpoint_roundtrip(tmp_path):
     assert t2.load(f) == (3, 77)
     for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_elementwise_diffusion_helpers_match_oracle():
+    """q_sample / posterior / eps<->x0 conversions (gaussian_diffusion.py:433-475,554-571) against the oracle's tables."""
+    import importlib, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    R = importlib.import_module("oracle.diffusion_ref")
+    D = pkg("diffusion")
+    steps = 50
+    d = D.GaussianDiffusion(betas=D.get_named_beta_schedule("linear", steps), model_mean_type=D.ModelMeanType.EPSILON,
+                            model_var_type=D.ModelVarType.FIXED_SMALL, loss_type=D.LossType.MSE)
+    tb = R.Tables(R.linear_betas(steps))
+    g = torch.Generator().manual_seed(3)
+    x, eps, x0 = (torch.randn(3, 5, 7, generator=g) for _ in range(3))
+    t = torch.tensor([0, 17, 49])
+    f = lambda arr: torch.tensor([tb.f32(arr, int(i)) for i in t])[:, None, None]
+    assert torch.equal(d._predict_xstart_from_eps(x, t, eps), f(tb.sqrt_recip_acp) * x - f(tb.sqrt_recipm1_acp) * eps)
+    assert torch.equal(d._predict_eps_from_xstart(x, t, x0), (f(tb.sqrt_recip_acp) * x - x0) / f(tb.sqrt_recipm1_acp))
+    mean, var, logvar = d.q_posterior_mean_variance(x0, x, t)
+    assert torch.equal(mean, f(tb.coef1) * x0 + f(tb.coef2) * x)
+    assert torch.equal(var, f(tb.post_var).expand_as(x)) and torch.equal(logvar, f(tb.post_logvar_clipped).expand_as(x))
+    q = d.q_sample(x0, t, noise=eps)
+    assert torch.equal(q, f(np.sqrt(tb.acp)) * x0 + f(np.sqrt(1.0 - tb.acp)) * eps)
+    m, v, lv = d.q_mean_variance(x0, t)
+    assert torch.equal(m, f(np.sqrt(tb.acp)) * x0) and torch.equal(v, f(1.0 - tb.acp).expand_as(x0))

@@ -117,3 +117,13 @@ def test_ddim_loop_matches_reference(eta):
     with torch.no_grad():
         y = DR.ddim_loop(model, tb, g["x_T"], noises(f"ddim.{eta}", meta["steps_ddim"]), eta=eta)
     assert rel_inf(y, g[f"ddim{eta}/final"]) < 2e-4
+
+
+def test_text_head_oracle_matches_reference_golden():
+    """oracle/text_head_ref.py against the reference's own EnhancedTextEncoder.forward output (DeBERTa fetch stubbed)."""
+    import text_head_ref as TR
+    g, meta = load_golden("text_head")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd/")}
+    pooled, projected = TR.text_head(g["hidden"], sd["prompt_tokens"], sd["proj.0.weight"], sd["proj.0.bias"],
+                                     sd["proj.1.weight"], sd["proj.1.bias"])
+    assert torch.equal(projected, g["projected"]) and torch.equal(pooled, g["pooled"])

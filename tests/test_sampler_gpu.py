@@ -137,3 +137,37 @@ def test_resample_mode_redraws_projections_like_the_reference():
     torch.manual_seed(5)
     c = m(*args, **kw).cpu()
     assert not torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_p_mean_variance_and_progressive_loops():
+    """API-surface methods around the HIP forward: p_mean_variance (gaussian_diffusion.py:481-552) against the oracle's
+    step arithmetic, and the *_progressive generators against the fused loops."""
+    import importlib, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    R = importlib.import_module("oracle.diffusion_ref")
+    g, meta, m, diff, noises, kw = _setup()
+    steps = meta["steps_ddim"]
+    d = diff(steps)
+    kw2 = {k: kw[k] for k in ("xf_proj", "xf_out", "length")}
+    x = g["x_T"].cuda()
+    B = x.shape[0]
+    tb = R.Tables(R.linear_betas(steps))
+    for t0 in (0, steps // 2, steps - 1):
+        t = torch.full((B,), t0, dtype=torch.int64, device="cuda")
+        out = d.p_mean_variance(m, x, t, clip_denoised=False, model_kwargs=kw2)
+        eps = m(x, t, **kw2).cpu()
+        mean_ref, x0_ref = R.cfg_step(tb, t0, x.cpu(), eps, None, torch.zeros_like(eps), 0.0, clip=False)
+        assert rel_inf(out["pred_xstart"].cpu(), x0_ref) < 1e-5
+        assert rel_inf(out["mean"].cpu(), mean_ref) < 1e-5
+        assert abs(float(out["log_variance"].flatten()[0]) - tb.f32(tb.post_logvar_clipped, t0)) < 1e-6
+    sn = noises("prog", steps)
+    full = d.ddim_sample_loop(m, tuple(x.shape), noise=x, model_kwargs=kw2, eta=0.5, step_noise=sn, use_graph=False)
+    last = None
+    n = 0
+    for out in d.ddim_sample_loop_progressive(m, tuple(x.shape), noise=x, model_kwargs=kw2, eta=0.5, step_noise=sn):
+        last, n = out, n + 1
+    assert n == steps and torch.equal(last["sample"], full)
+    full = d.p_sample_loop(m, tuple(x.shape), noise=x, clip_denoised=False, model_kwargs=kw2, step_noise=sn, use_graph=False)
+    for out in d.p_sample_loop_progressive(m, tuple(x.shape), noise=x, clip_denoised=False, model_kwargs=kw2, step_noise=sn):
+        last = out
+    assert torch.equal(last["sample"], full)
