@@ -246,6 +246,16 @@ int mdm_text_head_forward(const float* hidden, const float* prompts, const float
                           int32_t Dt, float* xf_out, float* xf_proj, void* ws, int64_t ws_bytes, int32_t precision,
                           void* stream);
 
+/* Post-processing of generated motions on the device (tools/visualization.py:21-27,89): de-normalise (x * std + mean),
+ * recover_from_ric (utils/motion_process.py:362-416: root rotation / translation by prefix sums, joints rotated back by
+ * the inverse root rotation) and the temporal gaussian filter of motion_temporal_filter (utils/utils.py:125-130).
+ * motion (B, T, feats) fp32, length (B) int32 or NULL (= T), mean / std (feats).  weights[0..radius]: the normalised
+ * gaussian taps w[k] = w[-k] as fp64 (radius 0 = no filter).  scratch and joints_out: (B, T, joints, 3) fp32; frames
+ * past a sample's length are written as zeros. */
+int mdm_motion_postprocess(const float* motion, const int32_t* length, const float* mean, const float* std, int32_t B,
+                           int32_t T, int32_t feats, int32_t joints, int32_t radius, const double* weights,
+                           float* scratch, float* joints_out, void* stream);
+
 /* small helpers used by the host module */
 int mdm_xattn_gate(const float* gate, const float* adaptive_gate, int32_t D, float* out, void* stream);
 int mdm_fill_i64(int64_t* dst, int64_t n, const int32_t* src_dev, void* stream);

@@ -53,6 +53,9 @@ int gated_mix_gather(const float* table, const int64_t* ts, int steps, const flo
                      uint16_t* out16, hipStream_t s);
 int text_assemble(const float* pp, const float* ph, int B, int N0, int P, int Dt, float* xf_out, float* xf_proj,
                   hipStream_t s);
+// motion_post.hip: 263-d HumanML3D rows -> (T, J, 3) joints, optional temporal gaussian filter (wts[0..radius])
+int motion_post(const float* x, const int* len, const float* mean, const float* sd, int B, int T, int feats, int J,
+                int radius, const double* wts, float* raw, float* out, hipStream_t s);
 int iota_i64(int64_t* dst, int64_t n, int64_t start, hipStream_t s);
 int xattn_gate(const float* gate, const float* ag, int D, float* out, hipStream_t s);
 int halve_lengths(const int* len, int B, int* out, hipStream_t s);

@@ -710,6 +710,18 @@ int mdm_text_head_forward(const float* hidden, const float* prompts, const float
   return text_assemble(pp, ph, B, N0, P, Dt, xf_out, xf_proj, s);
 }
 
+// generated motions -> joint positions (tools/visualization.py:21-27,89; utils/motion_process.py:362-416; utils/utils.py:125-130)
+int mdm_motion_postprocess(const float* motion, const int32_t* length, const float* mean, const float* std, int32_t B,
+                           int32_t T, int32_t feats, int32_t joints, int32_t radius, const double* weights,
+                           float* scratch, float* joints_out, void* stream) {
+  if (!motion || !mean || !std || !scratch || !joints_out || B <= 0 || T <= 0 || joints < 1 || radius < 0 ||
+      (radius > 0 && !weights))
+    return MDM_ERR_ARG;
+  if (feats < 4 + 3 * (joints - 1)) return MDM_ERR_ARG;
+  return motion_post(motion, length, mean, std, B, T, feats, joints, radius, weights, scratch, joints_out,
+                     (hipStream_t)stream);
+}
+
 int mdm_cfg_posterior_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n,
                            const float* tab, int32_t steps, const int32_t* t_dev, int32_t t_imm, float cfg_scale,
                            int32_t clip_denoised, float* x_out, float* x0_out, void* stream) {

@@ -68,3 +68,58 @@ def sample_sharded(sample_fn, shape, model_kwargs: Dict, seed: int, steps_with_n
     local_kw = shard_kwargs(model_kwargs, lo, hi)
     local = sample_fn((hi - lo,) + tuple(shape[1:]), local_kw, x_T[lo:hi], [s[lo:hi] for s in step] if step else None)
     return all_gather_ragged(local, B, group)
+
+
+# ---- evaluation-scale generation: length-bucketed batches dealt over the ranks --------------
+def plan_buckets(m_lens, batch_size: int, max_frames: int, unit: int = 1):
+    """Replace the reference's serial ``while cur_idx < N`` batching (ddpm_trainer.py:176-199), which pads every batch to
+    its longest sample, by batches of similar length: samples sorted by (clamped) length, longest first, cut every
+    ``batch_size``.  Returns [(indices (LongTensor), T)], T = that batch's frame count (rounded up to ``unit``)."""
+    lens = torch.as_tensor(m_lens).flatten().long().clamp(max=max_frames)
+    order = torch.sort(lens, descending=True, stable=True).indices
+    plan = []
+    for lo in range(0, len(order), batch_size):
+        idx = order[lo:lo + batch_size]
+        T = int(lens[idx].max())
+        T = min(max_frames, (T + unit - 1) // unit * unit)
+        plan.append((idx, T))
+    return plan
+
+
+def padded_frames(plan) -> int:
+    """sum over batches of B_i * T_i: the work the plan schedules (the serial plan's figure is its baseline)."""
+    return sum(len(idx) * T for idx, T in plan)
+
+
+def run_plan(plan, run_bucket, n: int, max_frames: int, feats: int, device, group=None):
+    """Deal the plan's batches round-robin over the ranks (batches are sorted by cost, so every rank gets a similar mix),
+    run ``run_bucket(bucket_id, indices, T) -> (len(indices), T, feats)`` on the local ones, and exchange the results
+    with ONE all_gather of a padded (per-rank samples, max_frames, feats) buffer.  Returns the list of per-sample
+    ``(T_bucket, feats)`` tensors in the ORIGINAL order, on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = [k for k in range(len(plan)) if k % world == rank]
+    per_rank = [sum(len(plan[k][0]) for k in range(len(plan)) if k % world == r) for r in range(world)]
+    cap = max(per_rank) if per_rank else 0
+    buf = torch.zeros((cap, max_frames, feats), dtype=torch.float32, device=device)
+    pos = 0
+    for k in mine:
+        idx, T = plan[k]
+        y = run_bucket(k, idx, T)
+        assert tuple(y.shape) == (len(idx), T, feats), (tuple(y.shape), len(idx), T, feats)
+        buf[pos:pos + len(idx), :T] = y
+        pos += len(idx)
+    if world > 1:
+        allb = torch.empty((world * cap, max_frames, feats), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(allb, buf, group=group)
+    else:
+        allb = buf
+    out = [None] * n
+    cursor = [0] * world
+    for k, (idx, T) in enumerate(plan):
+        r = k % world
+        base = r * cap + cursor[r]
+        for j, i in enumerate(idx.tolist()):
+            out[i] = allb[base + j, :T].clone()
+        cursor[r] += len(idx)
+    return out

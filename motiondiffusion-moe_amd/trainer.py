@@ -62,6 +62,46 @@ class DDPMTrainer(object):
             cur += batch_size
         return all_output
 
+    @torch.no_grad()
+    def generate_bucketed(self, caption, m_lens, dim_pose, batch_size=32, *, unit_length=4, seed=None, group=None,
+                          progress=False):
+        """Evaluation-scale variant of ``generate``: same inputs and the same kind of result (a
+        list of per-sample ``(T_batch, dim_pose)`` tensors in the caller's order, valid up to each sample's length),
+        but batches hold samples of similar length (less padded work) and, under ``torch.distributed``, are dealt over
+        the ranks with one all_gather at the end.  ``seed`` makes every batch's noise a function of (seed, batch id)."""
+        from . import dist as D
+        m = self._model()
+        self.eval_mode()
+        lens = torch.as_tensor(m_lens).flatten().long().cpu()
+        plan = D.plan_buckets(lens, batch_size, m.num_frames, unit_length)
+
+        def run_bucket(k, idx, T):
+            if seed is not None:
+                torch.manual_seed(int(seed) + k)
+            cap = [caption[i] for i in idx.tolist()]
+            ln = lens[idx].clamp(max=T).to(self.device)
+            xf_proj, xf_out = m.encode_text(cap, self.device)
+            return self.diffusion.p_sample_loop_with_cfg(
+                m, (len(cap), T, dim_pose), clip_denoised=False, progress=progress,
+                model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out, "length": ln, "text": cap}, cfg_scale=self.cfg_scale)
+
+        return D.run_plan(plan, run_bucket, len(caption), m.num_frames, dim_pose, self.device, group)
+
+    @torch.no_grad()
+    def generate_joints(self, caption, m_lens, dim_pose, mean, std, batch_size=8, *, joints_num=22, sigma=1.0,
+                        bucketed=False, **kw):
+        """``generate`` followed by the reference's post-processing (tools/visualization.py:21-27,89) on the device:
+        list of ``(m_len, joints_num, 3)`` joint positions, temporally smoothed with a gaussian of width ``sigma``."""
+        from .postprocess import motion_to_joints
+        gen = self.generate_bucketed if bucketed else self.generate
+        motions = gen(caption, m_lens, dim_pose, batch_size, **kw)
+        lens = [min(int(n), mo.shape[0]) for n, mo in zip(torch.as_tensor(m_lens).flatten().tolist(), motions)]
+        x = torch.zeros((len(motions), max(mo.shape[0] for mo in motions), dim_pose), device=motions[0].device)
+        for i, mo in enumerate(motions):
+            x[i, :mo.shape[0]] = mo
+        j = motion_to_joints(x, mean, std, torch.tensor(lens), joints_num, sigma)  # one launch for all samples
+        return [j[i, :n] for i, n in enumerate(lens)]
+
     def save(self, file_name, ep, total_it):
         state = {"opt_encoder": getattr(self, "opt_encoder_state", {}), "ep": ep, "total_it": total_it,
                  "encoder": self._model().state_dict()}

@@ -338,6 +338,27 @@ def case_text_head():
     print("text_head:", tuple(pooled.shape), tuple(projected.shape))
 
 
+def case_motion_post():
+    """recover_from_ric (utils/motion_process.py:403-416) and motion_temporal_filter (utils/utils.py:125-130) of the
+    reference on seeded motions, driven exactly as tools/visualization.py:21-27,89 does."""
+    import utils.motion_process as MP
+    import utils.utils as UU
+    B, T, Fe = 3, 24, 263
+    motion = synth.uniform_pm1((B, T, Fe), "motion_post.x", 41) * (3.0 ** 0.5)
+    mean = synth.uniform_pm1((Fe,), "motion_post.mean", 41).numpy() * 0.2
+    std = (0.5 + 0.25 * synth.uniform_pm1((Fe,), "motion_post.std", 41)).numpy()
+    lengths = [24, 17, 8]
+    out = {"motion": motion, "mean": torch.from_numpy(mean), "std": torch.from_numpy(std),
+           "length": torch.tensor(lengths, dtype=torch.int64)}
+    for b, n in enumerate(lengths):
+        data = motion[b, :n].numpy() * std + mean                                   # visualization.py:89
+        joint = MP.recover_from_ric(torch.from_numpy(data).float(), 22).numpy()      # :22
+        out[f"joints_raw/{b}"] = torch.from_numpy(joint.copy())
+        out[f"joints/{b}"] = torch.from_numpy(UU.motion_temporal_filter(joint, sigma=1))  # :24
+    save("motion_post", out, {"B": B, "T": T, "feats": Fe, "joints": 22, "sigma": 1, "seed": 41})
+    print("motion_post:", {k: tuple(v.shape) for k, v in out.items() if k.startswith("joints/")})
+
+
 def cfgd(D, F_, H, Dt, E, L, size="small", frames=196, feats=263, **extra):
     d = dict(input_feats=feats, num_frames=frames, latent_dim_arg=D, ff_size_arg=F_, num_heads=H,
              text_latent_dim_arg=Dt, moe_num_experts=E, num_layers=L, model_size=size)
@@ -351,8 +372,12 @@ def main():
     if "--text-head-only" in sys.argv:
         case_text_head()
         return
+    if "--motion-post-only" in sys.argv:
+        case_motion_post()
+        return
     if "--loops-only" not in sys.argv:
         case_text_head()
+        case_motion_post()
         case_layout()
         case_projection_qr()
         case_forward("fwd_tiny", cfgd(64, 128, 4, 32, 4, 1, frames=16), B=2, T=16, N=6, wseed=11, iseed=21)

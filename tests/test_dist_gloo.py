@@ -61,3 +61,46 @@ def test_shard_ranges_cover_batch():
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
     sk = dmod.shard_kwargs({"a": torch.arange(6), "t": list("abcdef"), "s": 3}, 2, 5)
     assert sk["a"].tolist() == [2, 3, 4] and sk["t"] == ["c", "d", "e"] and sk["s"] == 3
+
+
+def _fake_bucket(k, idx, T):
+    # per-sample values that depend only on the sample index and the batch's frame count
+    return (idx.float().view(-1, 1, 1) + 1) * torch.ones(len(idx), T, 3) + 0.001 * T
+
+
+def _plan_worker(rank, world, port, lens, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dmod = pkg("dist")
+    plan = dmod.plan_buckets(lens, 3, 16, 4)
+    ran = []
+    y = dmod.run_plan(plan, lambda k, idx, T: (ran.append(k), _fake_bucket(k, idx, T))[1], len(lens), 16, 3, "cpu")
+    assert ran == [k for k in range(len(plan)) if k % world == rank]
+    if rank == 1:
+        torch.save(y, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_plan_and_two_rank_exchange(tmp_path):
+    dmod = pkg("dist")
+    lens = [16, 5, 9, 40, 8, 12, 4, 7, 11, 3]
+    plan = dmod.plan_buckets(lens, 3, 16, 4)
+    seen = torch.cat([idx for idx, _ in plan]).tolist()
+    assert sorted(seen) == list(range(len(lens))) and all(len(idx) <= 3 for idx, _ in plan)
+    clamped = [min(l, 16) for l in lens]
+    for idx, T in plan:
+        assert T % 4 == 0 and T <= 16 and T >= max(clamped[i] for i in idx.tolist()) > T - 4
+    assert [T for _, T in plan] == sorted((T for _, T in plan), reverse=True)
+    serial = [(torch.arange(lo, min(lo + 3, len(lens))), max(clamped[lo:lo + 3])) for lo in range(0, len(lens), 3)]
+    assert dmod.padded_frames(plan) <= dmod.padded_frames(serial)
+    single = dmod.run_plan(plan, _fake_bucket, len(lens), 16, 3, "cpu")
+    for i, y in enumerate(single):
+        T = next(T for idx, T in plan if i in idx.tolist())
+        assert y.shape == (T, 3) and torch.all(y == (i + 1) + 0.001 * T)
+    out = str(tmp_path / "plan.pt")
+    mp.spawn(_plan_worker, args=(2, _free_port(), lens, out), nprocs=2, join=True)
+    two = torch.load(out)
+    assert len(two) == len(single) and all(torch.equal(a, b) for a, b in zip(two, single))

@@ -127,3 +127,14 @@ def test_text_head_oracle_matches_reference_golden():
     pooled, projected = TR.text_head(g["hidden"], sd["prompt_tokens"], sd["proj.0.weight"], sd["proj.0.bias"],
                                      sd["proj.1.weight"], sd["proj.1.bias"])
     assert torch.equal(projected, g["projected"]) and torch.equal(pooled, g["pooled"])
+
+
+def test_motion_post_oracle_matches_reference_golden():
+    """oracle/motion_ref.py against the reference's recover_from_ric + motion_temporal_filter outputs."""
+    import motion_ref as MR
+    g, meta = load_golden("motion_post")
+    for b, n in enumerate(g["length"].tolist()):
+        j = MR.motion_to_joints(g["motion"][b, :n], g["mean"].numpy(), g["std"].numpy(), 22, 1.0)
+        assert np.array_equal(j, g[f"joints/{b}"].numpy()), b
+        r = MR.motion_to_joints(g["motion"][b, :n], g["mean"].numpy(), g["std"].numpy(), 22, 0.0)
+        assert np.array_equal(r, g[f"joints_raw/{b}"].numpy()), b

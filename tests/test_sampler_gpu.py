@@ -171,3 +171,31 @@ def test_p_mean_variance_and_progressive_loops():
     for out in d.p_sample_loop_progressive(m, tuple(x.shape), noise=x, clip_denoised=False, model_kwargs=kw2, step_noise=sn):
         last = out
     assert torch.equal(last["sample"], full)
+
+
+def test_bucketed_generation_and_joints():
+    """generate_bucketed (length-sorted batches, caller's order restored) and generate_joints (device post-processing)."""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import motion_ref as MR
+    g, meta, m, diff, noises, kw = _setup()
+    Tr = pkg("trainer")
+    m.text_encoder_fn = lambda text, device: (g["xf_proj"][:1].expand(len(text), -1).to(device),
+                                              g["xf_out"][:1].expand(len(text), -1, -1).to(device))
+    args = types.SimpleNamespace(device=torch.device("cuda"), diffusion_steps=25, is_train=False, cfg_scale=2.5)
+    tr = Tr.DDPMTrainer(args, m)
+    caps, lens = ["a", "b", "c", "d", "e"], torch.tensor([8, 16, 12, 16, 4])
+    outs = tr.generate_bucketed(caps, lens, 263, batch_size=2, unit_length=4, seed=3)
+    # batches by length: {1, 3} at T = 16, {2, 0} at T = 12, {4} at T = 4; results come back in the caller's order
+    assert [o.shape for o in outs] == [(12, 263), (16, 263), (12, 263), (16, 263), (4, 263)]
+    assert all(torch.isfinite(o).all() for o in outs)
+    again = tr.generate_bucketed(caps, lens, 263, batch_size=2, unit_length=4, seed=3)
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))
+    mean = (np.linspace(-0.1, 0.1, 263)).astype(np.float32)
+    std = (np.linspace(0.5, 1.5, 263)).astype(np.float32)
+    joints = tr.generate_joints(caps, lens, 263, mean, std, batch_size=2, bucketed=True, unit_length=4, seed=3)
+    for i, (j, n) in enumerate(zip(joints, lens.tolist())):
+        assert j.shape == (n, 22, 3)
+        ref = MR.motion_to_joints(outs[i][:n].cpu(), mean, std, 22, 1.0)
+        assert rel_inf(j.cpu(), torch.from_numpy(ref)) < 5e-6, i
