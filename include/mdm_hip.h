@@ -154,6 +154,8 @@ typedef struct MdmLayer { /* MoEExtendedDecoderLayer, transformer.py:17-64 */
   /* MemoryEfficientCrossAttentionBlock, fast_attention.py:274-330 */
   MdmPacked sd_q, sd_k, sd_v, sd_out, sd_f1, sd_f2;
   const float *sd_q_b, *sd_k_b, *sd_v_b, *sd_out_b, *sd_ln_w, *sd_ln_b, *sd_f1_b, *sd_f2_b;
+  /* optional fp32 copies of sd_cross_attn.query / .out weights [D, D]: needed only to build the folded text cache */
+  const float *sd_q_w32, *sd_out_w32;
 } MdmLayer;
 
 typedef struct MdmModel { /* MotionTransformer, transformer.py:166-361 */
@@ -175,6 +177,11 @@ typedef struct MdmTextCache {
   float* sd_k;   /* [2L, B, N, D]       key(xf)   of fast_attention.py:306 */
   float* sd_v;   /* [2L, B, N, D]       value(xf) of fast_attention.py:307 */
   int32_t B, N;
+  /* optional (all three or none; throughput mode, D == 512, H * N <= 128): the query / output projections of the text
+   * cross-attention folded into the text side, see csrc/sdfold.hip.  Zero-initialised by the caller (padding). */
+  uint16_t* sd_kfold; /* bf16 [2L, B, 128, D]   K'[h*N + n, :] = key_h[n, :] Wq_h / sqrt(dh) */
+  float* sd_cb;       /* fp32 [2L, B, 128]      key_h[n, :] . bq_h / sqrt(dh) */
+  uint16_t* sd_vfold; /* bf16 [2L, B, D, 128]   V'^T[:, h*N + n] = Wout[:, h] value_h[n, :]^T */
 } MdmTextCache;
 
 /* Optional per-loop stem cache: the time-embedding chain (time.py:15-31 -> time_embed -> time_proj -> gated_fusion.proj_time,

@@ -76,7 +76,7 @@ class Layer(C.Structure):
                 ("sd_q", Packed), ("sd_k", Packed), ("sd_v", Packed), ("sd_out", Packed), ("sd_f1", Packed),
                 ("sd_f2", Packed), ("sd_q_b", C.c_void_p), ("sd_k_b", C.c_void_p), ("sd_v_b", C.c_void_p),
                 ("sd_out_b", C.c_void_p), ("sd_ln_w", C.c_void_p), ("sd_ln_b", C.c_void_p), ("sd_f1_b", C.c_void_p),
-                ("sd_f2_b", C.c_void_p)]
+                ("sd_f2_b", C.c_void_p), ("sd_q_w32", C.c_void_p), ("sd_out_w32", C.c_void_p)]
 
 
 _MODEL_PACKED = ["tmlp0", "tmlp2", "te0", "te2", "tproj", "gf_time", "gf_text", "gf_post0", "gf_post2", "text_proj",
@@ -94,7 +94,7 @@ class Model(C.Structure):
 
 class TextCache(C.Structure):
     _fields_ = [("lin_at", C.c_void_p), ("sd_k", C.c_void_p), ("sd_v", C.c_void_p), ("B", C.c_int32),
-                ("N", C.c_int32)]
+                ("N", C.c_int32), ("sd_kfold", C.c_void_p), ("sd_cb", C.c_void_p), ("sd_vfold", C.c_void_p)]
 
 
 class StemCache(C.Structure):

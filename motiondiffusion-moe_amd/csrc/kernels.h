@@ -46,6 +46,11 @@ bool xattn_supported(int dh, int N);
 int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
             float* out32, hipStream_t s);
 int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s);
+// sdfold.hip: text cross-attention with folded projections + the following LayerNorm, one launch
+bool sd_fold_supported(int D, int H, int N);
+int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const uint16_t* vfold, const float* bout,
+            const float* ln_w, const float* ln_b, int B, int S, int D, int H, int N, float* out32, uint16_t* out16,
+            hipStream_t s);
 int col_softmax(float* k, int B, int N, int D, hipStream_t s);
 int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s);
 int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s);

@@ -327,11 +327,28 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
 }
 
 // MemoryEfficientCrossAttentionBlock (fast_attention.py:301-330); out must not alias x
+struct SdFold {  // folded text side of one layer (MdmTextCache.sd_kfold / sd_cb / sd_vfold), or nulls
+  const uint16_t* kfold = nullptr;
+  const float* cb = nullptr;
+  const uint16_t* vfold = nullptr;
+};
+
 int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float* vc, const float* x, const uint16_t* x16,
-                  float* out, uint16_t* out16) {
+                  float* out, uint16_t* out16, const SdFold& fold = SdFold()) {
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H, N = c.N;
   const Work& w = c.w;
+  if (c.bf && fold.kfold && g_bf16_variant != 22 && sd_fold_supported(D, H, N)) {
+    // throughput mode: query GEMM + attention core + output GEMM + LayerNorm in one launch (csrc/sdfold.hip)
+    MDM_TRY(sd_fold(x16, fold.kfold, fold.cb, fold.vfold, l.sd_out_b, l.sd_ln_w, l.sd_ln_b, c.B, c.S, D, H, N, w.t3,
+                    (uint16_t*)w.t4, c.s));
+    LinOpts o1;
+    o1.act = ACT_GELU;
+    MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, w.f1, o1));
+    LinOpts o;  // x + (o + ffn(o))
+    o.R1 = x, o.R2 = w.t3;
+    return linear(c, act_of(c, w.f1), c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, out16, o);
+  }
   {
     LinOpts o;
     o.alpha = 1.f / sqrtf((float)dh);
@@ -389,6 +406,15 @@ const float* tc_k(const MdmModel& m, const MdmTextCache& tc, int layer) {
 const float* tc_v(const MdmModel& m, const MdmTextCache& tc, int layer) {
   return tc.sd_v + (int64_t)layer * tc.B * tc.N * m.D;
 }
+SdFold tc_fold(const MdmModel& m, const MdmTextCache& tc, int layer) {
+  SdFold f;
+  if (tc.sd_kfold && tc.sd_cb && tc.sd_vfold) {
+    f.kfold = tc.sd_kfold + (int64_t)layer * tc.B * 128 * m.D;
+    f.cb = tc.sd_cb + (int64_t)layer * tc.B * 128;
+    f.vfold = tc.sd_vfold + (int64_t)layer * tc.B * m.D * 128;
+  }
+  return f;
+}
 
 // one MoEExtendedDecoderLayer (transformer.py:55-64): x (+ bf16 shadow x16) is updated in place, (y, y16) is scratch
 int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, float* x, uint16_t* x16, float* y, uint16_t* y16,
@@ -408,7 +434,7 @@ int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, float* x, uin
   MDM_TRY(dump(1, x));
   MDM_TRY(moe_block(c, l, x, sc4 + 3 * scs, forced, y, y16));
   MDM_TRY(dump(2, y));
-  MDM_TRY(sdcross_block(c, l, tc_k(m, tc, layer), tc_v(m, tc, layer), y, y16, x, x16));
+  MDM_TRY(sdcross_block(c, l, tc_k(m, tc, layer), tc_v(m, tc, layer), y, y16, x, x16, tc_fold(m, tc, layer)));
   return dump(3, x);
 }
 
@@ -537,6 +563,49 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
     MDM_TRY(gemm(g, c.s));
     MDM_TRY(linear(c, act_f32(xf_out), BN, m->Dt, l.sd_k, l.sd_k_b, D, (float*)tc_k(*m, *tc, layer), nullptr));
     MDM_TRY(linear(c, act_f32(xf_out), BN, m->Dt, l.sd_v, l.sd_v_b, D, (float*)tc_v(*m, *tc, layer), nullptr));
+    if (tc->sd_kfold && tc->sd_cb && tc->sd_vfold) {
+      // fold the query / output projections into the text side (csrc/sdfold.hip), fp32-grade arithmetic, bf16 results
+      if (!l.sd_q_w32 || !l.sd_out_w32 || H * N > 128) return MDM_ERR_ARG;
+      const SdFold f = tc_fold(*m, *tc, layer);
+      const float scale = 1.f / sqrtf((float)dh);
+      const float* kc = tc_k(*m, *tc, layer);
+      const float* vc = tc_v(*m, *tc, layer);
+      {  // K'[b][h*N + n][j] = scale * sum_d key[b,n,h*dh+d] Wq[h*dh+d, j]
+        GemmArgs g = gemm_defaults(3);
+        g.A = op_f32(kc, D);
+        g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
+        g.W = op_f32_kstride(l.sd_q_w32, D);
+        g.W.bs1 = 0, g.W.bs2 = (int64_t)dh * D;
+        g.M = N, g.N = D, g.K = dh;
+        g.batch = B * H, g.nb2 = H;
+        g.alpha = scale;
+        g.C16 = (uint16_t*)f.kfold, g.ldc = D, g.c_bs1 = (int64_t)128 * D, g.c_bs2 = (int64_t)N * D;
+        MDM_TRY(gemm(g, c.s));
+      }
+      {  // cb[b][h*N + n] = scale * key[b,n,h*dh:] . bq[h*dh:]
+        GemmArgs g = gemm_defaults(3);
+        g.A = op_f32(kc, D);
+        g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
+        g.W = op_f32(l.sd_q_b, dh);
+        g.W.bs1 = 0, g.W.bs2 = dh;
+        g.M = N, g.N = 1, g.K = dh;
+        g.batch = B * H, g.nb2 = H;
+        g.alpha = scale;
+        g.C = (float*)f.cb, g.ldc = 1, g.c_bs1 = 128, g.c_bs2 = N;
+        MDM_TRY(gemm(g, c.s));
+      }
+      {  // V'^T[b][j][h*N + n] = sum_d Wout[j, h*dh+d] value[b,n,h*dh+d]
+        GemmArgs g = gemm_defaults(3);
+        g.A = op_f32(l.sd_out_w32, D);
+        g.A.bs1 = 0, g.A.bs2 = dh;
+        g.W = op_f32(vc, D);
+        g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
+        g.M = D, g.N = N, g.K = dh;
+        g.batch = B * H, g.nb2 = H;
+        g.C16 = (uint16_t*)f.vfold, g.ldc = 128, g.c_bs1 = (int64_t)D * 128, g.c_bs2 = N;
+        MDM_TRY(gemm(g, c.s));
+      }
+    }
   }
   return MDM_OK;
 }
@@ -648,7 +717,8 @@ int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const Mdm
     case MDM_BLOCK_CROSS: return cross_block(c, l, tc_at(*m, *tc, layer), h, sc + 2 * scs, out);
     case MDM_BLOCK_MOE: return moe_block(c, l, h, sc + 3 * scs, forced_routing, out, nullptr);
     case MDM_BLOCK_SDCROSS:
-      return sdcross_block(c, l, tc_k(*m, *tc, layer), tc_v(*m, *tc, layer), h, c.w.h016, out, nullptr);
+      return sdcross_block(c, l, tc_k(*m, *tc, layer), tc_v(*m, *tc, layer), h, c.w.h016, out, nullptr,
+                           tc_fold(*m, *tc, layer));
     case MDM_BLOCK_LAYER: {
       if (hipMemcpyAsync(c.w.xa, h, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) != hipSuccess) return MDM_ERR_LAUNCH;
       if (c.bf) MDM_TRY(to_bf16(h, n, c.w.xa16, c.s));

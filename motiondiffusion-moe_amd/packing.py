@@ -98,6 +98,8 @@ def kernel_layout(sd: Dict[str, torch.Tensor], cfg: dict, eph: Dict[str, Tuple[t
                         ("sd_f2", "ffn.3")):
             out["W:" + k + nm], out["V:" + k + nm + "_b"] = sd[f"{s}.{src}.weight"], sd[f"{s}.{src}.bias"]
         out[f"V:{k}sd_ln_w"], out[f"V:{k}sd_ln_b"] = sd[s + ".ffn.0.weight"], sd[s + ".ffn.0.bias"]
+        # fp32 copies for the folded text cache (K' = K Wq, V' = V Wout^T are built once per caption batch)
+        out[f"V:{k}sd_q_w32"], out[f"V:{k}sd_out_w32"] = sd[s + ".query.weight"], sd[s + ".out.weight"]
         # emb_w was appended in slot order local, global, cross, ffn -- same as STYLE_SLOTS
         for slot in STYLE_SLOTS:
             w, b = eph[f"{tag}.{slot}"]
@@ -184,6 +186,7 @@ class PackedModel:
         for nm in ("ca_q", "ca_k", "ca_v", "sd_q", "sd_k", "sd_v", "sd_out", "sd_f1", "sd_f2"):
             setattr(l, nm, self._packed(k + nm))
             setattr(l, nm + "_b", V[k + nm + "_b"].data_ptr())
+        l.sd_q_w32, l.sd_out_w32 = V[k + "sd_q_w32"].data_ptr(), V[k + "sd_out_w32"].data_ptr()
         gvec = torch.empty(D, dtype=torch.float32, device=V[k + "ca_gate"].device)
         L.check(L.lib().mdm_xattn_gate(C.c_void_p(V[k + "ca_gate"].data_ptr()), C.c_void_p(V[k + "ca_adaptive"].data_ptr()),
                                        C.c_int32(D), C.c_void_p(gvec.data_ptr()), C.c_void_p(L.stream_ptr())),

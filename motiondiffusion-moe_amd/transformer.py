@@ -288,11 +288,18 @@ class MotionTransformer(nn.Module):
         sv = torch.empty((L2, B, N, D), dtype=torch.float32, device=dev)
         tc = L.TextCache()
         tc.lin_at, tc.sd_k, tc.sd_v, tc.B, tc.N = at.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, N
+        fold = ()
+        if self.precision == 1 and D == 512 and H * N <= 128:
+            # throughput mode: query / output projections of the text cross-attention folded into the text side
+            fold = (torch.zeros((L2, B, 128, D), dtype=torch.bfloat16, device=dev),
+                    torch.zeros((L2, B, 128), dtype=torch.float32, device=dev),
+                    torch.zeros((L2, B, D, 128), dtype=torch.bfloat16, device=dev))
+            tc.sd_kfold, tc.sd_cb, tc.sd_vfold = (t.data_ptr() for t in fold)
         ws = self._workspace(B, 2, N)
         L.check(L.lib().mdm_text_cache_build(C.byref(pm.model), C.c_void_p(xf_out.data_ptr()), C.byref(tc),
                                              C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
                                              C.c_void_p(L.stream_ptr())), "mdm_text_cache_build")
-        cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out), "B": B, "N": N, "pm": pm}
+        cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out) + fold, "B": B, "N": N, "pm": pm}
         if not private:
             self._text_cache = cache
         return cache

@@ -93,3 +93,23 @@ def test_free_routing_flip_budget_bf16():
     flipped = int((tok_err > 0.1).sum())
     print("tokens with O(1) change (routing flips):", flipped, "of", B * S)
     assert flipped <= 1
+
+
+@pytest.mark.parametrize("S,N,B", [(196, 28, 3), (98, 28, 2), (50, 9, 1), (12, 32, 2)])
+def test_sd_fold_matches_unfolded_chain(S, N, B):
+    """Throughput mode: the text cross-attention with folded projections (csrc/sdfold.hip, one launch) against the
+    oracle and against the unfolded chain (query GEMM, attention core, output GEMM, LayerNorm; kernel knob 22)."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, 1)
+    L = pkg("_lib")
+    with torch.no_grad():
+        ref = R.softmax_cross_ffn(h, xf, sd, pre + ".sd_cross_attn", H)
+    folded = _run_block(m, L.BLOCK_SDCROSS, h, sc, length, xf)
+    L.lib().mdm_set_gemm_variant(22)
+    try:
+        chain = _run_block(m, L.BLOCK_SDCROSS, h, sc, length, xf)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    e_f, e_c, d = rel_inf(folded, ref), rel_inf(chain, ref), rel_inf(folded, chain)
+    print(f"S={S} N={N}: folded {e_f:.2e}  chain {e_c:.2e}  folded-vs-chain {d:.2e}")
+    assert e_f < TOL[1] and e_c < TOL[1]
+    assert not torch.equal(folded, chain)  # the knob really selects two different code paths
