@@ -207,9 +207,10 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     o.act = ACT_GELU;
     MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, p.proj0, p.proj0_b, D, w.t2, o));
   }
-  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, p.proj3, p.proj3_b, D, w.t4, nullptr));
+  const bool t16 = c.bf && g_bf16_variant != 25;  // the projection's output feeds a LayerNorm only: bf16 in throughput mode
+  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, p.proj3, p.proj3_b, D, t16 ? nullptr : w.t4, t16 ? (uint16_t*)w.t4 : nullptr));
   // post_norm, normalize * sqrt(D), stylization, y = x + 0.1 * style (:169-178)
-  return style_apply(c, p.style, w.t4, p.post_w, p.post_b, nullptr, sc, w.t2, x, 0.1f, nullptr, out);
+  return style_apply(c, p.style, w.t4, p.post_w, p.post_b, nullptr, sc, w.t2, x, 0.1f, nullptr, out, nullptr, t16);
 }
 
 // DualSelfAttentionBlock (fast_attention.py:208-226): x -> out.  Uses t1..t5.  x16: bf16 shadow of x (throughput mode)
@@ -286,8 +287,10 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
   f.C = w.y2, f.ldc = D;
   if (c.bf && g_bf16_variant != 21 && fused_mlp_supported(f)) {  // variant 21: two-GEMM chain, for A/B runs
     // throughput mode: both expert GEMMs in one kernel, hidden activations stay in LDS (switch_moe.py:19-25,104-109)
+    const bool y16 = g_bf16_variant != 25;  // expert outputs stored as bf16 (what autocast does to a Linear); knob 25: fp32
+    if (y16) f.C = nullptr, f.C16 = (uint16_t*)w.y2;
     MDM_TRY(fused_mlp(f, c.s));
-    return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, false);
+    return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, y16);
   }
   {
     GemmArgs g = gemm_defaults(c.prec);  // hidden = GELU(LN_b(x)[routed rows] W1_e^T + b1_e)

@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__
       }
 #pragma unroll
       for (int j = 0; j < NE; ++j) r.e[j] = ((a.e[j] + b.e[j]) + (c.e[j] + d.e[j])) * 0.5f;
+    } else if (x_bf) {
+      r.load_bf16((const uint16_t*)x + row * D, D, lane);
     } else {
       r.load(x + row * D, D, lane);
     }
