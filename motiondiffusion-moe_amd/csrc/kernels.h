@@ -25,8 +25,9 @@ struct MoeGateParams {
 };
 
 // y1/y2/out: fp32 tensors, or bf16 (uint16_t) when the matching *_bf flag is set
+// x_bf: the input rows are bf16 (throughput mode tensors whose only consumer is this LayerNorm)
 int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, void* y1, int y1_bf, const float* w2,
-             const float* b2, void* y2, int y2_bf, hipStream_t s);
+             const float* b2, void* y2, int y2_bf, hipStream_t s, int x_bf = 0);
 int style_in(const float* x, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw,
              const float* sb, const float* sc, const int* pos4, int x_bf, void* out, int out_bf, hipStream_t s);
 int to_bf16(const float* src, int64_t n, uint16_t* dst, hipStream_t s);
@@ -45,7 +46,8 @@ int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
 bool xattn_supported(int dh, int N);
 int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
             float* out32, hipStream_t s);
-int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s);
+int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
+              hipStream_t s);
 // sdfold.hip: text cross-attention with folded projections + the following LayerNorm, one launch
 bool sd_fold_supported(int D, int H, int N);
 int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const uint16_t* vfold, const float* bout,

@@ -127,7 +127,7 @@ struct Row {
 
 // ---- LN chain: y1 = LN1(x), y2 = LN2(y1) --------------------------------------------------------
 template <int NE, bool VEC>
-__global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, int64_t M, int D,
+__global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, int x_bf, int64_t M, int D,
                                                        const float* w1, const float* b1, void* y1, int y1_bf,
                                                        const float* w2, const float* b2, void* y2, int y2_bf) {
   const int lane = threadIdx.x & 63;
@@ -135,8 +135,13 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
   for (int64_t row = 2 * (blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6)); row < M; row += 2 * (int64_t)gridDim.x * WPB) {
     const bool two = row + 1 < M;
     Row<NE, VEC> r, q;
-    r.load(x + row * D, D, lane);
-    q.load(x + (two ? row + 1 : row) * D, D, lane);
+    if (x_bf) {
+      r.load_bf16((const uint16_t*)x + row * D, D, lane);
+      q.load_bf16((const uint16_t*)x + (two ? row + 1 : row) * D, D, lane);
+    } else {
+      r.load(x + row * D, D, lane);
+      q.load(x + (two ? row + 1 : row) * D, D, lane);
+    }
     r.layernorm(w1, b1, D, lane);
     q.layernorm(w1, b1, D, lane);
     if (y1) {
@@ -775,11 +780,11 @@ inline int unit_grid(int64_t units, int G) {
 }  // namespace
 
 int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, void* y1, int y1_bf, const float* w2,
-             const float* b2, void* y2, int y2_bf, hipStream_t s) {
+             const float* b2, void* y2, int y2_bf, hipStream_t s, int x_bf) {
   if (M <= 0) return MDM_OK;
   if (!x || !w1 || !b1 || (w2 && (!b2 || !y2)) || (!w2 && !y1)) return MDM_ERR_ARG;
 #define CALL(NE, VEC) \
-  hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid((M + 1) / 2)), dim3(256), 0, s, x, M, D, w1, b1, y1, y1_bf, w2, b2, y2, y2_bf)
+  hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid((M + 1) / 2)), dim3(256), 0, s, x, x_bf, M, D, w1, b1, y1, y1_bf, w2, b2, y2, y2_bf)
   MDM_ROW_DISPATCH(D, CALL);
 #undef CALL
   MDM_RETURN_IF_LAUNCH_FAILED();

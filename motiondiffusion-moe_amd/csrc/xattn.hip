@@ -140,7 +140,7 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
 
 template <bool IN16>
 __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__ ql, const float* __restrict__ at, int S,
-                                                        int H, float* __restrict__ out) {
+                                                        int H, float* __restrict__ out, uint16_t* __restrict__ out16) {
   __shared__ __attribute__((aligned(16))) uint16_t aL[DH * PS];  // A^T [l][d]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
@@ -182,7 +182,12 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
         const frag_t af = *(const frag_t*)(aL + (16 * lt + r16) * PS + 32 * ks + 8 * q);
         y[lt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, qf[ks], y[lt], 0, 0, 0);  // D[l][t]
       }
-    if (t < S) {
+    if (t < S && out16) {
+      uint16_t* orow = out16 + ((int64_t)b * S + t) * D + h * DH;
+#pragma unroll
+      for (int lt = 0; lt < 8; ++lt)
+        *(uint2*)(orow + 16 * lt + 4 * q) = make_uint2(pack_bf16(y[lt][0], y[lt][1]), pack_bf16(y[lt][2], y[lt][3]));
+    } else if (t < S) {
       float* orow = out + ((int64_t)b * S + t) * D + h * DH;
 #pragma unroll
       for (int lt = 0; lt < 8; ++lt) *(f32x4*)(orow + 16 * lt + 4 * q) = y[lt];
@@ -212,13 +217,14 @@ int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, 
   return MDM_OK;
 }
 
-int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s) {
+int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
+              hipStream_t s) {
   if (dh != DH) return MDM_ERR_UNSUPPORTED;
-  if (!ql || !at || !out) return MDM_ERR_ARG;
+  if (!ql || !at || (!out && !out16)) return MDM_ERR_ARG;
   if (ql_bf16) {
-    hipLaunchKernelGGL(lin_xattn_kernel<true>, dim3(B * H), dim3(XNT), 0, s, ql, at, S, H, out);
+    hipLaunchKernelGGL(lin_xattn_kernel<true>, dim3(B * H), dim3(XNT), 0, s, ql, at, S, H, out, out16);
   } else {
-    hipLaunchKernelGGL(lin_xattn_kernel<false>, dim3(B * H), dim3(XNT), 0, s, ql, at, S, H, out);
+    hipLaunchKernelGGL(lin_xattn_kernel<false>, dim3(B * H), dim3(XNT), 0, s, ql, at, S, H, out, out16);
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
