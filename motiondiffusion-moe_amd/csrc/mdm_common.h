@@ -35,7 +35,7 @@ __device__ __forceinline__ void split_bf16(float a, float b, uint32_t& hi, uint3
 }
 
 // erf(x) as the odd rational P(x^2) x / Q(x^2) on [-4, 4] (|erf| = 1 beyond to fp32 precision): max abs error
-// 3.8e-7 against libm over [-6, 6] (checked in tests/test_numerics.py), ~16 instructions, no branches.  The
+// 3.8e-7 against libm over [-6, 6] (checked in tests/test_host_logic.py), ~16 instructions, no branches.  The
 // libm erff inlined 64x per thread dominated the GEMM epilogues.
 __device__ __forceinline__ float erf_fast(float x) {
   x = fminf(fmaxf(x, -4.f), 4.f);

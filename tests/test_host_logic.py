@@ -159,3 +159,29 @@ def test_elementwise_diffusion_helpers_match_oracle():
     assert torch.equal(q, f(np.sqrt(tb.acp)) * x0 + f(np.sqrt(1.0 - tb.acp)) * eps)
     m, v, lv = d.q_mean_variance(x0, t)
     assert torch.equal(m, f(np.sqrt(tb.acp)) * x0) and torch.equal(v, f(1.0 - tb.acp).expand_as(x0))
+
+
+def test_erf_rational_of_the_kernels_is_accurate():
+    """The branch-free rational erf used by every GELU epilogue (csrc/mdm_common.h: erf_fast): its coefficients are read
+    from the header and evaluated in fp32 exactly as the kernel does (Horner with fused multiply-adds emulated in
+    fp64 -> fp32 rounding per step); max abs error against scipy's erf over [-6, 6] must stay below 5e-7."""
+    import os, re
+    from scipy.special import erf
+    from conftest import ROOT
+    src = open(os.path.join(ROOT, "motiondiffusion-moe_amd", "csrc", "mdm_common.h")).read()
+    body = src[src.index("float erf_fast(float x)"):src.index("float gelu_erf(float x)")]
+    nums = [float(v) for v in re.findall(r"(-?\d\.\d+e[-+]\d+)f", body)]
+    assert len(nums) == 12, nums
+    p_c, q_c = nums[:7], nums[7:]
+    x = np.linspace(-6, 6, 200001).astype(np.float32)
+    xc = np.clip(x, -4, 4)
+    x2 = (xc * xc).astype(np.float32)
+
+    def horner(cs):
+        acc = np.full_like(x2, np.float32(cs[0]))
+        for c in cs[1:]:
+            acc = (acc.astype(np.float64) * x2.astype(np.float64) + np.float64(np.float32(c))).astype(np.float32)  # fmaf
+        return acc
+
+    approx = (xc * horner(p_c)).astype(np.float32) / horner(q_c)
+    assert float(np.abs(approx.astype(np.float64) - erf(x.astype(np.float64))).max()) < 5e-7
