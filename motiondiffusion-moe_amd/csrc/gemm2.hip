@@ -126,6 +126,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     for (int i = 0; i < PPWW; ++i) glds16(pw[i] + k0, sw + i * 1024);
   };
 
+  // the first K tiles go out BEFORE anything else touches the memory pipeline: the epilogue constants below are not
+  // needed for ~20 K cycles, the tiles are needed at once
+  const int nk = g.K / BK;
+  MDM_STAMP(1);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, s);
+  MDM_STAMP(2);
+
   // column / row constants of this lane's outputs, fetched before the K loop (they ride in 40 registers)
   float* __restrict__ C = g.C ? g.C + offC : nullptr;
   uint16_t* __restrict__ C16 = g.C16 ? g.C16 + offC : nullptr;
@@ -137,15 +146,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   const int nbase = nt * BN + wn * 64 + fq * 4;
   float bv[4][4], cv[4][4], rs[MI];
   bool keymask[MI];
+  const bool vec_n = nt * BN + BN <= g.N && (!bias || ((((uintptr_t)bias) & 15) == 0 && (offB & 3) == 0)) &&
+                     (!colscale || (((uintptr_t)colscale) & 15) == 0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j) {
+    if (vec_n) {  // four consecutive columns per lane: one 16-byte load each instead of four dword loads
+      const f32x4 b4 = bias ? *(const f32x4*)(bias + nbase + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 c4 = colscale ? *(const f32x4*)(colscale + nbase + j * 16) : (f32x4){1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nbase + j * 16 + r;
-      const int nn = n < g.N ? n : g.N - 1;
-      bv[j][r] = bias ? bias[nn] : 0.f;
-      cv[j][r] = g.out_scale * (colscale ? colscale[nn] : 1.f);
+      for (int r = 0; r < 4; ++r) bv[j][r] = b4[r], cv[j][r] = g.out_scale * c4[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nbase + j * 16 + r;
+        const int nn = n < g.N ? n : g.N - 1;
+        bv[j][r] = bias ? bias[nn] : 0.f;
+        cv[j][r] = g.out_scale * (colscale ? colscale[nn] : 1.f);
+      }
     }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = row0 + wm * (BM / 2) + i * 16 + (lane & 15);
@@ -166,13 +185,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = g.K / BK;
-  MDM_STAMP(1);
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nk) stage(s, s);
-  MDM_STAMP(2);
 
   constexpr int PIECES = PPA + PPWW;  // LDS-DMA instructions per wave per K-tile
   const int frow = lane & 15;
