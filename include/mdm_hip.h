@@ -220,6 +220,25 @@ int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const Mdm
                       const float* sc, const int32_t* len, int32_t B, int32_t S, float* out, void* ws, int64_t ws_bytes,
                       const int32_t* forced_routing, int32_t precision, void* stream);
 
+/* The same blocks under the names SURVEY.md 8(b) lists (thin views of mdm_block_forward; sc4 = the layer's four
+ * (scale|shift) rows [4, B, 2D] as above), plus one PerformerSelfAttention alone (fast_attention.py:137-179; which = 0
+ * local_attn, 1 global_attn; sc = that block's (scale|shift) rows [B, 2D]; out = x + 0.1 * style(...)). */
+int mdm_moe_ffn_forward(const MdmModel* m, int32_t layer, const float* h, const float* sc4, const int32_t* len, int32_t B,
+                        int32_t S, float* out, void* ws, int64_t ws_bytes, const int32_t* forced_routing,
+                        int32_t precision, void* stream);
+int mdm_dual_self_attn_forward(const MdmModel* m, int32_t layer, const float* h, const float* sc4, const int32_t* len,
+                               int32_t B, int32_t S, float* out, void* ws, int64_t ws_bytes, int32_t precision,
+                               void* stream);
+int mdm_linear_xattn_forward(const MdmModel* m, int32_t layer, const MdmTextCache* tc, const float* h, const float* sc4,
+                             const int32_t* len, int32_t B, int32_t S, float* out, void* ws, int64_t ws_bytes,
+                             int32_t precision, void* stream);
+int mdm_softmax_xattn_ffn_forward(const MdmModel* m, int32_t layer, const MdmTextCache* tc, const float* h,
+                                  const float* sc4, const int32_t* len, int32_t B, int32_t S, float* out, void* ws,
+                                  int64_t ws_bytes, int32_t precision, void* stream);
+int mdm_performer_attn_forward(const MdmModel* m, int32_t layer, int32_t which, const float* h, const float* sc,
+                               const int32_t* len, int32_t B, int32_t S, float* out, void* ws, int64_t ws_bytes,
+                               int32_t precision, void* stream);
+
 /* StylizationBlock.forward given (scale|shift) = emb_layers(emb): out = Lin(SiLU(LN(h)*(1+scale)+shift)) */
 int mdm_stylization_forward(const MdmStyle* st, const float* h, const float* sc, int32_t B, int32_t S, int32_t D,
                             float* tmp, float* out, int32_t precision, void* stream);

@@ -737,6 +737,47 @@ int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const Mdm
   }
 }
 
+// ---- per-block entry points named as SURVEY.md §8(b) lists them: thin views of mdm_block_forward -----------------------
+int mdm_moe_ffn_forward(const MdmModel* m, int32_t layer, const float* h, const float* sc4, const int32_t* len, int32_t B,
+                        int32_t S, float* out, void* ws, int64_t ws_bytes, const int32_t* forced_routing,
+                        int32_t precision, void* stream) {
+  return mdm_block_forward(m, layer, MDM_BLOCK_MOE, nullptr, h, sc4, len, B, S, out, ws, ws_bytes, forced_routing, precision,
+                           stream);
+}
+int mdm_dual_self_attn_forward(const MdmModel* m, int32_t layer, const float* h, const float* sc4, const int32_t* len,
+                               int32_t B, int32_t S, float* out, void* ws, int64_t ws_bytes, int32_t precision,
+                               void* stream) {
+  return mdm_block_forward(m, layer, MDM_BLOCK_DUAL, nullptr, h, sc4, len, B, S, out, ws, ws_bytes, nullptr, precision, stream);
+}
+int mdm_linear_xattn_forward(const MdmModel* m, int32_t layer, const MdmTextCache* tc, const float* h, const float* sc4,
+                             const int32_t* len, int32_t B, int32_t S, float* out, void* ws, int64_t ws_bytes,
+                             int32_t precision, void* stream) {
+  return mdm_block_forward(m, layer, MDM_BLOCK_CROSS, tc, h, sc4, len, B, S, out, ws, ws_bytes, nullptr, precision, stream);
+}
+int mdm_softmax_xattn_ffn_forward(const MdmModel* m, int32_t layer, const MdmTextCache* tc, const float* h,
+                                  const float* sc4, const int32_t* len, int32_t B, int32_t S, float* out, void* ws,
+                                  int64_t ws_bytes, int32_t precision, void* stream) {
+  return mdm_block_forward(m, layer, MDM_BLOCK_SDCROSS, tc, h, sc4, len, B, S, out, ws, ws_bytes, nullptr, precision, stream);
+}
+// one PerformerSelfAttention (fast_attention.py:137-179): which = 0 local_attn, 1 global_attn; sc = that block's
+// (scale|shift) rows [B, 2D]
+int mdm_performer_attn_forward(const MdmModel* m, int32_t layer, int32_t which, const float* h, const float* sc,
+                               const int32_t* len, int32_t B, int32_t S, float* out, void* ws, int64_t ws_bytes,
+                               int32_t precision, void* stream) {
+  MDM_TRY(check_model(m));
+  if (!h || !sc || !len || !out || !ws || B <= 0 || S <= 0 || layer < 0 || layer >= 2 * m->L || which < 0 || which > 1)
+    return MDM_ERR_ARG;
+  Ctx c = {};
+  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B, c.S = S,
+  c.M = (int64_t)B * S, c.len = len, c.N = 1;
+  c.w = carve(*m, B, S, 1, ws);
+  if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
+  const MdmLayer& l = m->layers[layer];
+  const MdmPerformer& p = which ? l.global : l.local;
+  MDM_TRY(ln_chain(h, c.M, m->D, p.pre_w, p.pre_b, c.w.t3, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  return performer(c, p, h, act_of(c, c.w.t3), sc, out);
+}
+
 int mdm_stylization_forward(const MdmStyle* st, const float* h, const float* sc, int32_t B, int32_t S, int32_t D,
                             float* tmp, float* out, int32_t precision, void* stream) {
   if (!st || !h || !sc || !tmp || !out || B <= 0 || S <= 0) return MDM_ERR_ARG;

@@ -113,3 +113,48 @@ def test_sd_fold_matches_unfolded_chain(S, N, B):
     print(f"S={S} N={N}: folded {e_f:.2e}  chain {e_c:.2e}  folded-vs-chain {d:.2e}")
     assert e_f < TOL[1] and e_c < TOL[1]
     assert not torch.equal(folded, chain)  # the knob really selects two different code paths
+
+
+@pytest.mark.parametrize("precision", [3, 1])
+def test_named_block_entry_points(precision):
+    """The per-block C entry points named in SURVEY.md §8(b): the aliases must reproduce mdm_block_forward bit for bit, and
+    mdm_performer_attn_forward (one PerformerSelfAttention) is checked against the oracle for both attention slots."""
+    B, S, N = 2, 98, 28
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, precision)
+    L = pkg("_lib")
+    lib = L.lib()
+    pm = m.pack()
+    tcache = m.prepare_text(xf.cuda())
+    ws = m._workspace(B, S, N)
+    hd, scd, ld = h.cuda().contiguous(), sc.cuda().contiguous(), length.to(torch.int32).cuda()
+    common = (C.c_void_p(hd.data_ptr()), C.c_void_p(scd.data_ptr()), C.c_void_p(ld.data_ptr()), C.c_int32(B), C.c_int32(S))
+    tail = (C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()))
+
+    def call(fn, *pre_args, extra=()):
+        out = torch.empty_like(hd)
+        L.check(fn(C.byref(pm.model), C.c_int32(0), *pre_args, *common, C.c_void_p(out.data_ptr()), *tail, *extra,
+                   C.c_int32(precision), C.c_void_p(L.stream_ptr())))
+        return out.cpu()
+
+    tc = C.byref(tcache["tc"])
+    null = C.c_void_p(0)
+    m.reset_all_moe_counters(m)
+    a_moe = call(lib.mdm_moe_ffn_forward, extra=(null,))
+    assert torch.equal(call(lib.mdm_dual_self_attn_forward), _run_block(m, L.BLOCK_DUAL, h, sc, length, xf))
+    assert torch.equal(call(lib.mdm_linear_xattn_forward, tc), _run_block(m, L.BLOCK_CROSS, h, sc, length, xf))
+    assert torch.equal(call(lib.mdm_softmax_xattn_ffn_forward, tc), _run_block(m, L.BLOCK_SDCROSS, h, sc, length, xf))
+    assert torch.equal(a_moe, _run_block(m, L.BLOCK_MOE, h, sc, length, xf))
+    mask = R.src_mask(S, length)
+    for which, slot in ((0, "local"), (1, "global")):
+        out = torch.empty_like(hd)
+        scw = sc[which].cuda().contiguous()
+        L.check(lib.mdm_performer_attn_forward(C.byref(pm.model), C.c_int32(0), C.c_int32(which), C.c_void_p(hd.data_ptr()),
+                                               C.c_void_p(scw.data_ptr()), C.c_void_p(ld.data_ptr()), C.c_int32(B),
+                                               C.c_int32(S), C.c_void_p(out.data_ptr()), *tail, C.c_int32(precision),
+                                               C.c_void_p(L.stream_ptr())))
+        with torch.no_grad():
+            ref = R.performer_self_attention(h, emb, mask, sd, f"{pre}.dual_self_attn.{slot}_attn", H,
+                                             eph[f"low.0.{slot}_style"], proj[f"low.0.{slot}"])
+        err = rel_inf(out.cpu(), ref)
+        print(f"performer {slot} precision {precision}: {err:.2e}")
+        assert err < TOL[precision], (slot, err)
