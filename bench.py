@@ -110,7 +110,11 @@ def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=32, nsteps=3)
         dt = (time.perf_counter() - t0) / nsteps
     full = dt * B / n
     print(f"[bench] cpu_baseline: {dt:.1f} s for the sample -> {full:.1f} s per full step", file=sys.stderr, flush=True)
-    return {"value": 1.0 / full, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        cpu_model = "unknown"
+    return {"value": 1.0 / full, "unit": "denoising-steps/sec", "cores": cores, "kind": "port", "cpu_model": cpu_model,
             "sample": f"{nsteps} CFG steps (2 forwards each) of the torch-CPU oracle (fp32) on {n} of the {B} samples, "
                       f"T={x.shape[1]}, {dt:.1f} s per step measured" + (f", scaled x{B / n:g} to the batch" if n != B else "")}
 
