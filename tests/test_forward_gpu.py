@@ -75,3 +75,43 @@ def test_rejects_cpu_and_odd_T():
     with pytest.raises(ValueError):
         m(g["x"][:, :15].cuda(), g["timesteps"].cuda(), g["length"].cuda(), xf_proj=g["xf_proj"].cuda(),
           xf_out=g["xf_out"].cuda())
+
+
+SHAPES = [(1, 2, 1), (1, 6, 5), (3, 30, 32), (2, 62, 33), (5, 14, 28), (2, 196, 85), (33, 4, 8), (4, 100, 31), (1, 196, 28)]
+
+
+@pytest.mark.parametrize("B,T,N", SHAPES)
+def test_forward_shape_sweep_both_modes(B, T, N):
+    """Odd shapes through every fused kernel and its fallback (T/2 odd, one frame pair, N at and past the folded
+    cross-attention's limit of 32 tokens, more samples than one wave of workgroups): both precision modes against the
+    oracle on the real small widths (D=512, 8 experts, one layer per scale), routing injected from the oracle."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import denoiser_ref as R
+    synth = pkg("synth")
+    g, meta = load_golden("fwd_small_dims")
+    seed = 100 + B + T + N
+    x = synth.uniform_pm1((B, T, 263), "sweep.x", seed) * (3.0 ** 0.5)
+    xf_out = synth.uniform_pm1((B, N, 256), "sweep.xf", seed) * (3.0 ** 0.5)
+    xf_proj = xf_out.mean(1)
+    gen = torch.Generator().manual_seed(seed)
+    length = torch.randint(1, T + 1, (B,), generator=gen)  # any length, not only multiples of 4
+    length[0] = T
+    ts = torch.randint(0, 1000, (B,), generator=gen)
+    trace = {}
+    m3, (sd, eph, proj, mcfg) = build_module(meta, precision=3)
+    with torch.no_grad():
+        ref = R.denoiser_forward(sd, mcfg, x, ts, length, xf_proj, xf_out, eph, proj, None, trace)
+    forced = torch.zeros((2, 2 * 2 * B * T), dtype=torch.int32)
+    for li, name in enumerate(_layer_names(1)):
+        idx = torch.stack([trace[f"{name}.ffn.branches.{b}.top2_idx"] for b in range(2)])
+        forced[li, :idx.numel()] = idx.reshape(-1).to(torch.int32)
+    dev = "cuda"
+    args = (x.to(dev), ts.to(dev), length.to(dev))
+    kw = dict(xf_proj=xf_proj.to(dev), xf_out=xf_out.to(dev))
+    e3 = rel_inf(m3(*args, **kw).cpu(), ref)
+    m1, _ = build_module(meta, precision=1)
+    e1 = rel_inf(m1(*args, forced_routing=forced, **kw).cpu(), ref)
+    print(f"B={B} T={T} N={N}: fp32-grade {e3:.2e}  bf16 {e1:.2e}")
+    assert e3 < TOL_FP32 and e1 < 5e-2
