@@ -250,6 +250,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     }
   }
   __syncthreads();  // every wave is done with the last K tile
+  MDM_STAMP(6);
   float* stg = (float*)smem;  // [BM][128] fp32
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     }
   }
   __syncthreads();
+  MDM_STAMP(7);
   if (fast) {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       }
     }
   }
+  MDM_STAMP(8);
   if (dbg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MDM_STAMP(5);

@@ -19,6 +19,10 @@ for (M, N, K, v) in [(128, 128, 512, 1), (6272, 512, 512, 1), (12544, 512, 512, 
     torch.cuda.synchronize()
     st = (C.c_uint64 * 16)()
     L.check(L.lib().mdm_debug_stamps(st))
-    t = [st[i] for i in range(6)]
-    print(f"M={M} N={N} K={K} variant={v}: total {(t[5]-t[0])} cycles (100MHz ticks? see below)")
-    for i in range(1, 6): print(f"    {names[i]:24s} +{t[i]-t[i-1]:8d}")
+    t = [st[i] for i in range(9)]
+    print(f"M={M} N={N} K={K} variant={v}: total {(t[5]-t[0])} cycles")
+    for i in range(1, 5): print(f"    {names[i]:24s} +{t[i]-t[i-1]:8d}")
+    print(f"    {'residuals issued + sync':24s} +{t[6]-t[4]:8d}")
+    print(f"    {'staging writes + sync':24s} +{t[7]-t[6]:8d}")
+    print(f"    {'LDS reads + stores issued':24s} +{t[8]-t[7]:8d}")
+    print(f"    {'stores drained':24s} +{t[5]-t[8]:8d}")
