@@ -190,6 +190,29 @@ class GaussianDiffusion:
         assert mean.shape == log_variance.shape == pred_xstart.shape == x.shape
         return {"mean": mean, "variance": variance, "log_variance": log_variance, "pred_xstart": pred_xstart}
 
+    @torch.no_grad()
+    def training_losses(self, model, x_start, t, model_kwargs=None, noise=None):
+        """The MSE branch of gaussian_diffusion.py:923-985 evaluated with the HIP forward: resets the MoE counters,
+        diffuses ``x_start`` to ``x_t``, runs the denoiser and returns {"mse", "target", "pred", "moe_loss"}.  These are
+        VALUES (validation loss, routing balance): the HIP path has no backward, training is outside this build."""
+        if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
+            raise NotImplementedError("only the MSE losses of the epsilon model are evaluated (ddpm_trainer.py:47)")
+        self._check_supported()
+        if model_kwargs is None:
+            model_kwargs = {}
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        x_t = self.q_sample(x_start, t, noise=noise)
+        terms = {}
+        model.reset_all_moe_counters(model)
+        model_output = model(x_t, self._scale_timesteps(t), **model_kwargs)
+        target = noise  # ModelMeanType.EPSILON
+        assert model_output.shape == target.shape == x_start.shape
+        terms["mse"] = ((target - model_output) ** 2).mean(dim=list(range(1, x_start.dim()))).view(-1)
+        terms["target"], terms["pred"] = target, model_output
+        terms["moe_loss"] = model.get_moe_loss(model)
+        return terms
+
     def _progressive(self, r, noise, step_noise):
         """Generator form of _StepRunner.run: yields {"sample", "pred_xstart"} after every step (eager launches)."""
         B = r.B

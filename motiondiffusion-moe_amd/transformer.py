@@ -194,19 +194,24 @@ class MotionTransformer(nn.Module):
         for b in (model or self).moe_buffers().values():
             b.zero_()
 
+    @staticmethod
+    def load_balancing_loss(usage: torch.Tensor, importance: torch.Tensor, epsilon: float = 1e-8) -> torch.Tensor:
+        """SwitchMoELayer.get_load_balancing_loss (switch_moe.py:113-145): E * (1 - sum_e usage_frac[e] * importance_frac[e])."""
+        u = usage / usage.sum().clamp_min(epsilon)
+        i = importance / importance.sum().clamp_min(epsilon)
+        return usage.numel() * (1.0 - (u * i).sum())
+
     def get_moe_loss(self, model=None):
-        """Sum over MoE layers of E * sum(importance_frac * usage_frac) (switch_moe.py:113-145); counters only,
-        i.e. the value the reference computes, without a graph (training is out of scope)."""
+        """Sum of the load-balancing losses of every SwitchMoE layer (transformer.py:272-279), from the device-side counters
+        the router kernels maintain; a value without a graph, like the reference's (its counters are updated under
+        no_grad, switch_moe.py:71-92)."""
         m = model or self
         bufs = m.moe_buffers()
         total = torch.zeros((), device=self.device)
         for k, usage in bufs.items():
             if not k.endswith("expert_usage"):
                 continue
-            imp = bufs[k.replace("expert_usage", "expert_importance")]
-            u = usage / usage.sum().clamp_min(1e-8)
-            i = imp / imp.sum().clamp_min(1e-8)
-            total = total + usage.numel() * (u * i).sum()
+            total = total + self.load_balancing_loss(usage, bufs[k.replace("expert_usage", "expert_importance")])
         return total
 
     def get_total_moe_loss(self, model=None, moe_coef=0.01):

@@ -359,6 +359,24 @@ def case_motion_post():
     print("motion_post:", {k: tuple(v.shape) for k, v in out.items() if k.startswith("joints/")})
 
 
+def case_moe_loss():
+    """SwitchMoELayer.get_load_balancing_loss (switch_moe.py:113-145) of the reference on given counters, and
+    MotionTransformer.get_moe_loss (transformer.py:272-279) summed over a model's layers."""
+    out = {}
+    for E in (4, 8):
+        with contextlib.redirect_stdout(io.StringIO()):
+            layer = RS.SwitchMoELayer(16, 32, num_experts=E)
+        usage = (synth.uniform_pm1((E,), f"moe_loss.usage{E}", 51).abs() * 100).round()
+        imp = synth.uniform_pm1((E,), f"moe_loss.imp{E}", 51).abs() * 37.0
+        layer.expert_usage.copy_(usage), layer.expert_importance.copy_(imp)
+        out[f"usage{E}"], out[f"importance{E}"] = usage, imp
+        out[f"loss{E}"] = layer.get_load_balancing_loss().detach().reshape(1)
+    layer.expert_usage.zero_(), layer.expert_importance.zero_()
+    out["loss_zero_counters"] = layer.get_load_balancing_loss().detach().reshape(1)
+    save("moe_loss", out, {"seed": 51})
+    print("moe_loss:", {k: float(v) for k, v in out.items() if k.startswith("loss")})
+
+
 def cfgd(D, F_, H, Dt, E, L, size="small", frames=196, feats=263, **extra):
     d = dict(input_feats=feats, num_frames=frames, latent_dim_arg=D, ff_size_arg=F_, num_heads=H,
              text_latent_dim_arg=Dt, moe_num_experts=E, num_layers=L, model_size=size)
@@ -375,9 +393,13 @@ def main():
     if "--motion-post-only" in sys.argv:
         case_motion_post()
         return
+    if "--moe-loss-only" in sys.argv:
+        case_moe_loss()
+        return
     if "--loops-only" not in sys.argv:
         case_text_head()
         case_motion_post()
+        case_moe_loss()
         case_layout()
         case_projection_qr()
         case_forward("fwd_tiny", cfgd(64, 128, 4, 32, 4, 1, frames=16), B=2, T=16, N=6, wseed=11, iseed=21)

@@ -185,3 +185,14 @@ def test_erf_rational_of_the_kernels_is_accurate():
 
     approx = (xc * horner(p_c)).astype(np.float32) / horner(q_c)
     assert float(np.abs(approx.astype(np.float64) - erf(x.astype(np.float64))).max()) < 5e-7
+
+
+def test_load_balancing_loss_matches_reference_golden():
+    """switch_moe.py:113-145 on given counters (tests/golden/moe_loss.npz, produced by the reference's own method)."""
+    T = pkg("transformer")
+    g, _ = load_golden("moe_loss")
+    for E in (4, 8):
+        got = T.MotionTransformer.load_balancing_loss(g[f"usage{E}"], g[f"importance{E}"])
+        assert torch.allclose(got.reshape(1), g[f"loss{E}"], rtol=1e-6, atol=1e-7), (E, got, g[f"loss{E}"])
+    z = torch.zeros(8)
+    assert torch.allclose(T.MotionTransformer.load_balancing_loss(z, z).reshape(1), g["loss_zero_counters"])

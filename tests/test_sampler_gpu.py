@@ -199,3 +199,32 @@ def test_bucketed_generation_and_joints():
         assert j.shape == (n, 22, 3)
         ref = MR.motion_to_joints(outs[i][:n].cpu(), mean, std, 22, 1.0)
         assert rel_inf(j.cpu(), torch.from_numpy(ref)) < 5e-6, i
+
+
+def test_training_losses_values_match_oracle():
+    """Forward-only evaluation of the reference's training objective (gaussian_diffusion.py:923-985): the MSE term against
+    the oracle's forward on the same x_t, and the load-balancing term against the oracle's counters."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import denoiser_ref as R
+    from conftest import golden_state
+    g, meta, m, diff, noises, kw = _setup()
+    d = diff(50)
+    x0 = g["x_T"] * 0.3
+    B = x0.shape[0]
+    t = torch.tensor([7, 31][:B])
+    noise = noises("train", 1)[0]
+    kw2 = {k: kw[k] for k in ("xf_proj", "xf_out", "length")}
+    terms = d.training_losses(m, x0.cuda(), t.cuda(), model_kwargs=kw2, noise=noise.cuda())
+    sd, eph, proj, mcfg = golden_state(meta)
+    x_t = d.q_sample(x0, t, noise=noise)
+    trace = {}
+    with torch.no_grad():
+        pred = R.denoiser_forward(sd, mcfg, x_t, t, g["length"], g["xf_proj"], g["xf_out"], eph, proj, None, trace)
+    mse = ((noise - pred) ** 2).mean(dim=(1, 2))
+    assert rel_inf(terms["pred"].cpu(), pred) < 1e-3
+    assert torch.allclose(terms["mse"].cpu(), mse, rtol=1e-3)
+    T = pkg("transformer")
+    want = sum(T.MotionTransformer.load_balancing_loss(trace[k], trace[k.replace(".usage", ".importance")])
+               for k in trace if k.endswith(".usage"))
+    assert abs(float(terms["moe_loss"]) - float(want)) < 1e-3 * max(1.0, abs(float(want)))
