@@ -63,29 +63,59 @@ __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// wave64 reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions.  Inside a row of 16 lanes they use DPP modifiers (quad_perm, row_half_mirror, row_mirror: plain
+// VALU instructions); __shfl_xor compiles to ds_bpermute_b32, an LDS-crossbar round trip of ~100+ cycles per step, and the
+// row-wise kernels (LayerNorm chains, stylization inputs, router) are chains of such reductions.  Rows are combined with
+// v_readlane (whole wave: the row totals are wave-uniform after the DPP steps) or one __shfl_xor per doubling (sub-wave
+// groups of 32 / 64 lanes).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+struct OpSum {
+  static __device__ __forceinline__ float f(float a, float b) { return a + b; }
+};
+struct OpMax {
+  static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); }
+};
+// reduce over aligned groups of W <= 16 lanes (every lane of the group gets the result)
+template <int W, typename Op>
+__device__ __forceinline__ float row_reduce(float v) {
+  if constexpr (W >= 2) v = Op::f(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]
+  if constexpr (W >= 4) v = Op::f(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]
+  if constexpr (W >= 8) v = Op::f(v, dpp_move<0x141>(v));  // row_half_mirror: lane i <- 7 - i within each 8
+  if constexpr (W >= 16) v = Op::f(v, dpp_move<0x140>(v)); // row_mirror: lane i <- 15 - i within each 16
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v) {
+  v = row_reduce<16, Op>(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return Op::f(Op::f(a, b), Op::f(c, d));
 }
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce<OpSum>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce<OpMax>(v); }
 // reductions over aligned sub-groups of W lanes (W power of two <= 64)
+template <int W, typename Op>
+__device__ __forceinline__ float group_reduce(float v) {
+  if constexpr (W == 64) {
+    return wave_reduce<Op>(v);
+  } else {
+    v = row_reduce<(W < 16 ? W : 16), Op>(v);
+    if constexpr (W == 32) v = Op::f(v, __shfl_xor(v, 16, 64));
+    return v;
+  }
+}
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return group_reduce<W, OpSum>(v);
 }
 template <int W>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return group_reduce<W, OpMax>(v);
 }
 
 // Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (8 XCDs, round-robin dispatch).
