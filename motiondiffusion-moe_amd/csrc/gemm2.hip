@@ -366,11 +366,14 @@ int gemm_bf16(const GemmArgs& a, hipStream_t stream) {
     if (g_bf16_variant == 6 || (a.K >= 2048 && t256 >= g_big_min_tiles)) return gemm_bf16_256(a, stream);
   }
   // few 128x128 tiles => the launch is a latency chain on <= 2 blocks per CU: halve the tile height so that every
-  // CU holds 3+ independent blocks (variant 1 / 2 force the 128- / 64-row tile for benchmarking)
+  // CU holds 3+ independent blocks (variant 1 / 2 force the 128- / 64-row tile for benchmarking).  The 64-row tile runs a
+  // 3-stage ring (72 KiB: still two blocks per CU; K tiles arrive two steps ahead): 5.90 -> 5.79 ms per step; for the
+  // 128-row tile a third stage costs the second resident block, and 32-wide K tiles in 3- / 4-deep rings change nothing
   const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + BN - 1) / BN) * a.batch;
   bool small = !a.goff && (tiles128 <= 256 || a.M <= 64);
   if (g_bf16_variant == 1) small = false;
   if (g_bf16_variant == 2) small = true;
+  if (small && g_bf16_variant != 28) return launch_bf16<64, 64, 3>(a, stream);  // 3-stage ring: still 2 blocks/CU, tiles arrive 2 ahead (knob 28: 2-stage)
   return small ? launch_bf16<64, 64, 2>(a, stream) : launch_bf16<128, 64, 2>(a, stream);
 }
 
