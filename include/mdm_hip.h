@@ -292,6 +292,13 @@ int mdm_set_gemm_variant(int variant);
 /* diagnostic: s_memtime stamps of block 0 of the last bf16 GEMM launched with feat_S == -77 (host copy, synchronises) */
 int mdm_debug_stamps(uint64_t* out16);
 
+/* Measurement probe for bench.py: while enabled, every launch of the dominant kernel (the fused expert MLP inside
+ * mdm_denoiser_forward / mdm_block_forward) is bracketed by a pair of HIP events recorded on the launch stream (do not
+ * enable during hipGraph capture).  mdm_probe_read synchronises the events and returns the number of launches recorded
+ * since the last enable, writing up to `cap` durations (microseconds) and row counts. */
+int mdm_probe_enable(int32_t enable);
+int mdm_probe_read(float* us, int32_t* rows, int32_t cap);
+
 const char* mdm_version(void);
 
 #ifdef __cplusplus

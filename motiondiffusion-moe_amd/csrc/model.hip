@@ -14,6 +14,17 @@ namespace {
     if (st__ != MDM_OK) return st__; \
   } while (0)
 
+// ---- measurement probe (mdm_probe_enable / mdm_probe_read): HIP events around the dominant kernel's launches -------
+constexpr int PROBE_MAX = 64;
+struct Probe {
+  bool on = false;
+  int n = 0;
+  hipEvent_t a[PROBE_MAX], b[PROBE_MAX];
+  int rows[PROBE_MAX];
+  bool made = false;
+};
+Probe g_probe;
+
 struct Bump {  // carve the caller's workspace; with base == nullptr it only measures
   uint8_t* base;
   int64_t off = 0;
@@ -293,7 +304,13 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     // throughput mode: both expert GEMMs in one kernel, hidden activations stay in LDS (switch_moe.py:19-25,104-109)
     const bool y16 = g_bf16_variant != 25;  // expert outputs stored as bf16 (what autocast does to a Linear); knob 25: fp32
     if (y16) f.C = nullptr, f.C16 = (uint16_t*)w.y2;
+    const bool pr = g_probe.on && g_probe.n < PROBE_MAX;
+    if (pr && hipEventRecord(g_probe.a[g_probe.n], c.s) != hipSuccess) return MDM_ERR_LAUNCH;
     MDM_TRY(fused_mlp(f, c.s));
+    if (pr) {
+      if (hipEventRecord(g_probe.b[g_probe.n], c.s) != hipSuccess) return MDM_ERR_LAUNCH;
+      g_probe.rows[g_probe.n++] = f.M;
+    }
     return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, y16);
   }
   {
@@ -838,6 +855,29 @@ int mdm_motion_postprocess(const float* motion, const int32_t* length, const flo
   if (feats < 4 + 3 * (joints - 1)) return MDM_ERR_ARG;
   return motion_post(motion, length, mean, std, B, T, feats, joints, radius, weights, scratch, joints_out,
                      (hipStream_t)stream);
+}
+
+int mdm_probe_enable(int32_t enable) {
+  if (enable && !g_probe.made) {
+    for (int i = 0; i < PROBE_MAX; ++i)
+      if (hipEventCreate(&g_probe.a[i]) != hipSuccess || hipEventCreate(&g_probe.b[i]) != hipSuccess) return MDM_ERR_LAUNCH;
+    g_probe.made = true;
+  }
+  g_probe.on = enable != 0;
+  if (enable) g_probe.n = 0;
+  return MDM_OK;
+}
+
+int mdm_probe_read(float* us, int32_t* rows, int32_t cap) {
+  const int n = g_probe.n;
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (hipEventSynchronize(g_probe.b[i]) != hipSuccess) return -1;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_probe.a[i], g_probe.b[i]) != hipSuccess) return -1;
+    if (us) us[i] = ms * 1e3f;
+    if (rows) rows[i] = g_probe.rows[i];
+  }
+  return n;
 }
 
 int mdm_cfg_posterior_step(const float* x, const float* eps_c, const float* eps_u, const float* noise, int64_t n,
