@@ -115,3 +115,27 @@ def test_forward_shape_sweep_both_modes(B, T, N):
     e1 = rel_inf(m1(*args, forced_routing=forced, **kw).cpu(), ref)
     print(f"B={B} T={T} N={N}: fp32-grade {e3:.2e}  bf16 {e1:.2e}")
     assert e3 < TOL_FP32 and e1 < 5e-2
+
+
+def test_probe_brackets_every_expert_mlp_launch():
+    """mdm_probe_enable / mdm_probe_read (bench.py's live timing of the dominant kernel): one event pair per fused expert
+    MLP launch of a throughput-mode forward, with that launch's routed-row count."""
+    import ctypes as C
+    L = pkg("_lib")
+    g, meta = load_golden("fwd_small_dims")
+    m, _ = build_module(meta, precision=1)
+    dev = "cuda"
+    args = (g["x"].to(dev), g["timesteps"].to(dev), g["length"].to(dev))
+    kw = dict(xf_proj=g["xf_proj"].to(dev), xf_out=g["xf_out"].to(dev))
+    m(*args, **kw)
+    lib = L.lib()
+    L.check(lib.mdm_probe_enable(1))
+    m(*args, **kw)
+    us, rows = (C.c_float * 8)(), (C.c_int32 * 8)()
+    n = lib.mdm_probe_read(us, rows, 8)
+    L.check(lib.mdm_probe_enable(0))
+    B, T, _ = g["x"].shape
+    assert n == 2  # one layer per scale in this golden config
+    assert [rows[i] for i in range(n)] == [4 * B * T // 2, 4 * B * T] and all(us[i] > 0 for i in range(n))
+    m(*args, **kw)
+    assert lib.mdm_probe_read(us, rows, 8) == 2  # disabled: nothing new is recorded
