@@ -258,11 +258,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 v;
+      f32x2 ge[2];
+      if constexpr (ACT == ACT_GELU) {  // packed-fp32 evaluation, two columns per instruction
+        ge[0] = gelu_erf2((f32x2){g.alpha * (acc[i][j][0] + bv[j][0]), g.alpha * (acc[i][j][1] + bv[j][1])});
+        ge[1] = gelu_erf2((f32x2){g.alpha * (acc[i][j][2] + bv[j][2]), g.alpha * (acc[i][j][3] + bv[j][3])});
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = g.alpha * (acc[i][j][r] + bv[j][r]);
         if constexpr (ACT == ACT_GELU) {
-          x = gelu_erf(x);
+          x = ge[r >> 1][r & 1];
         } else if constexpr (ACT == ACT_SILU) {
           x = silu(x);
         } else if constexpr (ACT == ACT_FEAT) {

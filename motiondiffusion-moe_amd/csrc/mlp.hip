@@ -155,8 +155,9 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = wm * 64 + i * 16 + frow;
-          const float v0 = gelu_erf(h[i][j][0] + bb[0]), v1 = gelu_erf(h[i][j][1] + bb[1]);
-          const float v2 = gelu_erf(h[i][j][2] + bb[2]), v3 = gelu_erf(h[i][j][3] + bb[3]);
+          const f32x2 g01 = gelu_erf2((f32x2){h[i][j][0] + bb[0], h[i][j][1] + bb[1]});
+          const f32x2 g23 = gelu_erf2((f32x2){h[i][j][2] + bb[2], h[i][j][3] + bb[3]});
+          const float v0 = g01[0], v1 = g01[1], v2 = g23[0], v3 = g23[1];
           // hidden chunk image: 512-B rows, 16-B chunk index (f >> 3) swizzled by (m & 15); 8-B half (f >> 2) & 1
           *(uint2*)(hc + m * 512 + (((f >> 3) ^ (m & 15)) << 4) + ((f >> 2) & 1) * 8) =
               make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
