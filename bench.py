@@ -28,7 +28,10 @@ CONFIGS = {
     "big": (dict(latent_dim=512, ff_size=1024, num_layers=4, num_heads=4, text_latent_dim=256, moe_num_experts=8,
                  model_size="big"), 3.5926e12, 1.349e12),
 }
-PEAK = {1: 2.5e15, 3: 2.5e15 / 3}  # dense bf16 MFMA; the bf16x3 mode issues 3 MFMAs per product
+# dense bf16 / fp16 MFMA peak (same rate); the bf16x3 mode issues 3 MFMAs per product; the mixed mode issues 3 per product
+# except in the expert MLPs + 4x FFN (52 % of the FLOPs at the small config: SURVEY.md section 8a): blended 1 / (0.48*3 + 0.52)
+PEAK = {1: 2.5e15, 2: 2.5e15, 3: 2.5e15 / 3, 4: 2.5e15 / (0.48 * 3 + 0.52)}
+DTYPE = {1: "bf16", 2: "f16", 3: "bf16x3(fp32-grade)", 4: "mixed(bf16x3 + f16 expert/FFN GEMMs)"}
 
 
 def build_model(cfg_name, device, precision, B, T, N, seed=0):
@@ -167,14 +170,16 @@ def expert_mlp_rate(m, B2, T):
     per launch = 4 * rows * D * F (two GEMMs).  Returns (seconds, flop) or None when the shape is not covered."""
     ops = importlib.import_module("motiondiffusion-moe_amd.ops")
     D, F_, E = m.latent_dim, m.ff_size, m.moe_num_experts
-    if D != 512 or F_ % 256 or m.precision != 1:
+    if D != 512 or F_ % 256 or m.precision not in (1, 2):
         return None
+    h16 = torch.float16 if m.precision == 2 else torch.bfloat16
+    fmt = "f16" if m.precision == 2 else "bf16"
     dev, M = m.device, B2 * T
     rows, G = 4 * M, 2 * E
     g = torch.Generator(device="cpu").manual_seed(0)
-    x16 = torch.randn(2 * M, D, generator=g).to(dev).to(torch.bfloat16)
-    w1 = ops.PackedWeight((torch.randn(G, F_, D, generator=g) * D ** -0.5).to(dev), with_lo=False)
-    w2 = ops.PackedWeight((torch.randn(G, D, F_, generator=g) * F_ ** -0.5).to(dev), with_lo=False)
+    x16 = torch.randn(2 * M, D, generator=g).to(dev).to(h16)
+    w1 = ops.PackedWeight((torch.randn(G, F_, D, generator=g) * D ** -0.5).to(dev), fmt=fmt)
+    w2 = ops.PackedWeight((torch.randn(G, D, F_, generator=g) * F_ ** -0.5).to(dev), fmt=fmt)
     b1, b2 = torch.zeros(G, F_, device=dev), torch.zeros(G, D, device=dev)
     gather = torch.randint(0, 2 * M, (rows,), generator=g, dtype=torch.int32).to(dev)
     goff = (torch.arange(G + 1, dtype=torch.int64) * rows // G).to(torch.int32).to(dev)
@@ -196,7 +201,6 @@ def probe_dominant_kernel(r, m, steps=3):
     r._step(True)  # warm the eager path
     L.check(lib.mdm_probe_enable(1))
     for _ in range(steps):
-        r.noise.normal_()
         r._step(True)
     torch.cuda.synchronize()
     us = (C.c_float * 64)()
@@ -212,13 +216,83 @@ def probe_dominant_kernel(r, m, steps=3):
     return t, flop, pairs
 
 
+def mode_table(a, m_main, inputs, host, diff, kw, dev, main_prec, main_ms, steps=10, warmup=3):
+    """Every precision mode on the SAME workload: ms per guided step (graph replay) and, for one forward of the cond half,
+    the error and the routing decisions that differ relative to the parity-grade mode (bf16x3; its own error against the
+    CPU oracle is gated in tests/test_round2_gpu.py).  No oracle is involved here: HIP against HIP on identical inputs."""
+    import ctypes as C
+    L = importlib.import_module("motiondiffusion-moe_amd._lib")
+    x, length, xf_proj, xf_out = inputs
+    B, T = x.shape[0], x.shape[1]
+    L2 = 2 * m_main.num_layers
+    t = torch.full((B,), a.schedule - 23, dtype=torch.int64, device=dev)
+    xd, ld = x.to(dev), length.to(dev)
+    res, outs, routes = {}, {}, {}
+    for prec in (3, 4, 2, 1):
+        if prec == main_prec:
+            m = m_main
+        else:
+            m, _, _ = build_model(a.config, dev, prec, B, T, xf_out.shape[1], seed=0)
+        dump = torch.full((L2, 2, B * T, 2), -1, dtype=torch.int32, device=dev)
+        L.lib().mdm_route_dump(C.c_void_p(dump.data_ptr()))
+        outs[prec] = m(xd, t, ld, xf_proj=kw["xf_proj"], xf_out=kw["xf_out"]).clone()
+        torch.cuda.synchronize()
+        L.lib().mdm_route_dump(C.c_void_p(0))
+        routes[prec] = dump.sort(-1).values
+        if prec == main_prec:
+            ms = main_ms
+        else:
+            r = diff._runner(m, (B, T, 263), kw, dev, "cfg", a.cfg_scale, 0.0, False, not a.no_graph, 1)
+            r.philox = (1234, 0)
+            r._prepare()
+            if r.use_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    r._step(True)
+                r.graph = g
+            r.xx[:B].copy_(r.draw_xT(1234, 0))
+            r.t_dev.fill_(a.schedule - 1)
+            step = (lambda: r.graph.replay()) if r.graph is not None else (lambda: r._step(True))
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            del r
+        res[prec] = {"precision": prec, "dtype": DTYPE[prec], "ms_per_step": round(ms, 3), "steps_per_s": round(1e3 / ms, 2)}
+        if prec != main_prec:
+            del m
+            torch.cuda.empty_cache()
+    ref, rref = outs[3], routes[3]
+    valid = int((rref[..., 0] >= 0).sum())
+    for prec in (4, 2, 1):
+        d = (outs[prec] - ref).abs()
+        frame = d.amax(-1) / ref.abs().amax()
+        res[prec].update({
+            "rel_err_vs_parity_mode": float(d.max() / ref.abs().max()),
+            "median_frame_err_vs_parity_mode": float(frame.median()),
+            "frames_off_by_5pct": int((frame > 0.05).sum()), "frames": int(frame.numel()),
+            "routing_decisions_that_differ": int(((routes[prec] != rref).any(-1) & (rref[..., 0] >= 0)).sum()),
+            "routing_decisions": valid})
+    res[3]["rel_err_vs_cpu_oracle"] = "<= 1e-3 gated (7e-5 measured) in tests/test_round2_gpu.py::test_configs1_free_routing_error_and_flip_budget"
+    out = {DTYPE[p].split("(")[0]: v for p, v in res.items() if p != 3}
+    out["parity_mode"] = res[3]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="small", choices=list(CONFIGS))
-    ap.add_argument("--precision", type=int, default=1, choices=[1, 3], help="1 = bf16 MFMA, 3 = bf16x3 fp32-grade")
+    ap.add_argument("--precision", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="1 = bf16 MFMA, 2 = fp16 MFMA (default: same speed, 8x smaller error), 3 = bf16x3 fp32-grade, "
+                         "4 = mixed (bf16x3 + fp16 expert/FFN GEMMs)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the per-mode timing / error table")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
     ap.add_argument("--frames", type=int, default=196)
     ap.add_argument("--schedule", type=int, default=1000)
@@ -251,20 +325,24 @@ def main():
                                 loss_type=D_.LossType.MSE)
     kw = {"xf_proj": xf_proj.to(dev), "xf_out": xf_out.to(dev), "length": length.to(dev), "text": ["synthetic"] * B}
     r = diff._runner(m, (B, T, 263), kw, dev, "cfg", a.cfg_scale, 0.0, False, not a.no_graph, a.streams)
+    r.philox = (1234, dmod.shard_range(B * world, rank, world)[0])
     r._prepare()
     if r.use_graph:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             r._step(True)
         r.graph = g
-    # world-size independent x_T: drawn for the global batch, sliced per rank
+    # world-size independent noise: x_T and every step's noise are functions of (seed, GLOBAL sample index, timestep,
+    # element) from the counter-based device generator (csrc/noise.hip); the step's noise draw is part of the captured graph
     lo, hi = dmod.shard_range(B * world, rank, world)
-    x_T, _ = dmod.global_noise((B * world, T, 263), seed=1234)
-    r.xx[:B].copy_(x_T[lo:hi].to(dev))
+    r.xx[:B].copy_(r.draw_xT(1234, lo))
     r.t_dev.fill_(a.schedule - 1)
+    done = [0]
 
     def one_step():
-        r.noise.normal_()
+        if done[0] and done[0] % a.schedule == 0:
+            r.t_dev.fill_(a.schedule - 1)  # a run longer than the schedule starts over instead of underflowing t
+        done[0] += 1
         if r.graph is not None:
             r.graph.replay()
         else:
@@ -302,16 +380,19 @@ def main():
         achieved = flop_step / (dt / a.steps)
         moe_dt, moe_flop = moe_block_rate(m, 2 * B, T, a.precision)
         dom = expert_mlp_rate(m, 2 * B, T)
+        done[0] = 0
+        r.t_dev.fill_(a.schedule - 1)
         live = probe_dominant_kernel(r, m) if not r.chunks else None  # single-stream steps only
+        modes = None if a.no_modes else mode_table(a, m, inputs, host, diff, kw, dev, a.precision, ms)
         traffic = None  # HBM-side bytes per step from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and (a.config, B, T, a.precision) == ("small", 32, 196, 1):
+        if os.path.exists(pmc) and (a.config, B, T, a.precision) == ("small", 32, 196, 1) and False:  # r01 passes: stale
             traffic = json.load(open(pmc))["total_bytes_per_step"]
         line = {
             "metric": "denoising-steps/sec (B=32, T=196, 263-d, 8 experts)", "value": round(value, 3),
             "unit": "denoising-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.precision == 1 else "bf16x3(fp32-grade)", "data": "synthetic",
+            "dtype": DTYPE[a.precision], "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if a.config == 'small' else 'configs[2]'}: model_size={a.config}, num_experts=8, B={B}/GPU, T={T}, "
                                    f"{a.schedule}-step DDPM with CFG {a.cfg_scale} (cond+uncond batched as {2 * B} rows), "
                                    f"N_text={N}, hipGraph={'on' if r.graph is not None else 'off'}, streams={r.nstreams if r.chunks else 1}",
@@ -352,6 +433,9 @@ def main():
                        "launches": [{"rows": rw, "us": round(u, 1)} for rw, u in live[2][:8]],
                        "timed_with": "HIP events recorded by the library on the launch stream around every launch of the "
                                      "kernel (mdm_probe_*), eager steps on the live sampler state after the timed region"})
+        if modes is not None:
+            line["parity_mode"] = modes.pop("parity_mode")
+            line["modes"] = modes
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host, inputs, a.schedule, a.cfg_scale)
         print(json.dumps(line), flush=True)

@@ -25,6 +25,17 @@ extern "C" {
 enum { MDM_OK = 0, MDM_ERR_ARG = 1, MDM_ERR_LAUNCH = 2, MDM_ERR_UNSUPPORTED = 3 };
 enum { MDM_OP_F32_ROW = 0, MDM_OP_F32_KSTRIDE = 1, MDM_OP_BF16_ROW = 2 };
 enum { MDM_ACT_NONE = 0, MDM_ACT_GELU = 1, MDM_ACT_SILU = 2, MDM_ACT_FEAT = 3 };
+/* 16-bit operand / storage format of the single-pass MFMA kernels: bf16, or IEEE fp16 (same MFMA rate on gfx950, 8x finer
+ * rounding, |x| <= 65504: used where the value range is known). */
+enum { MDM_H16_BF16 = 1, MDM_H16_F16 = 2 };
+/* `precision` of the model-level entry points:
+ *   1  single bf16 MFMA pass, GEMM-only tensors stored bf16 (throughput; BASELINE configs[1] names bf16)
+ *   2  single fp16 MFMA pass, GEMM-only tensors stored fp16 (same speed, ~8x smaller error)
+ *   3  bf16x3 split products everywhere, fp32 activations (fp32-grade: the mode that meets the 1e-3 parity bar)
+ *   4  mixed: bf16x3 for everything that feeds the fp32 residual stream and the MoE router, single fp16 pass for the
+ *      MFMA-bound GEMMs only (expert MLPs, the 4x FFN of the text cross-attention block)
+ * The packed weights must be in the matching format (packing.py: weight_format). */
+enum { MDM_PREC_BF16 = 1, MDM_PREC_F16 = 2, MDM_PREC_X3 = 3, MDM_PREC_MIXED = 4 };
 
 /* One GEMM operand: a [rows x K] matrix seen through a loader kind (see csrc/gemm.h). */
 typedef struct MdmOperand {
@@ -65,7 +76,8 @@ typedef struct MdmGemmDesc {
   int64_t ldr2;
   const int32_t* feat_len; /* ACT_FEAT key masking (fast_attention.py:69-74) */
   int32_t feat_S, feat_rpt, feat_kslot;
-  int32_t precision;
+  int32_t precision; /* 1 single pass, 3 bf16x3; 2 = single pass with fp16 operands (sets h16) */
+  int32_t h16;       /* MDM_H16_*: format of BF16_ROW activation / weight planes in the single-pass kernels and of C16 */
 } MdmGemmDesc;
 
 int mdm_gemm(const MdmGemmDesc* desc, void* stream);
@@ -98,8 +110,9 @@ typedef struct MdmMlpDesc {
   const float* R2;
   int64_t ldr2;
   float* C;      /* fp32 output (may be NULL when C16 is set) */
-  uint16_t* C16; /* optional bf16 copy */
+  uint16_t* C16; /* optional 16-bit copy */
   int64_t ldc;
+  int32_t h16;   /* MDM_H16_*: format of X, w1, w2 and C16 (0 = bf16) */
 } MdmMlpDesc;
 
 int mdm_fused_mlp(const MdmMlpDesc* desc, void* stream);
@@ -108,11 +121,13 @@ int mdm_fused_mlp(const MdmMlpDesc* desc, void* stream);
  * lo may be NULL.  Weight packing happens once at load time (not on the hot path). */
 int mdm_pack_bf16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* hi, uint16_t* lo,
                   int64_t ld_dst, void* stream);
+/* same layout, one IEEE fp16 plane (MDM_H16_F16 weights of the single-pass kernels) */
+int mdm_pack_f16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* dst, int64_t ld_dst, void* stream);
 
 /* ---- packed weights of one denoiser (built once at load time by motiondiffusion-moe_amd/packing.py) ------------ */
-typedef struct MdmPacked { /* bf16 planes of an fp32 [N,K] weight, K padded to ld (multiple of 32) */
-  const uint16_t* hi;
-  const uint16_t* lo; /* NULL when only precision 1 is needed */
+typedef struct MdmPacked { /* 16-bit planes of an fp32 [N,K] weight, K padded to ld (multiple of 32) */
+  const uint16_t* hi; /* bf16 hi plane, or the fp16 plane of a weight packed for a single fp16 pass */
+  const uint16_t* lo; /* bf16 lo plane (bf16x3), NULL otherwise */
   int64_t ld;
 } MdmPacked;
 
@@ -261,6 +276,14 @@ int mdm_ddim_step(const float* x, const float* eps, const float* noise, int64_t 
                   const int32_t* t_dev, int32_t t_imm, float eta, int32_t clip_denoised, float* x_out, float* x0_out,
                   void* stream);
 
+/* Counter-based gaussian noise (Philox4x32-10 + Box-Muller, csrc/noise.hip): out[s, e] for s < nsamples, e < per_sample is
+ * a function of (seed, sample0 + s, stream, e) only, where stream = *stream_dev when non-NULL (the device-resident timestep
+ * of a captured step) else stream_imm (MDM_NOISE_STREAM_XT for the initial x_T).  Replaces th.randn(*shape) /
+ * th.randn_like(x) of gaussian_diffusion.py:1119,1094 where results must not depend on how the batch is sharded. */
+enum { MDM_NOISE_STREAM_XT = 0x7fffffff };
+int mdm_noise_normal(float* out, int64_t per_sample, int32_t nsamples, int64_t sample0, uint64_t seed,
+                     const int32_t* stream_dev, int32_t stream_imm, void* stream);
+
 /* Text projection head of the reference's EnhancedTextEncoder (text_encoder.py:13-18,31-43), applied to the
  * last_hidden_state of any text encoder (the DeBERTa weights themselves are third-party and stay outside this library):
  *   projected[b] = GELU(Linear(LayerNorm(cat(prompt_tokens, hidden[b]))))   (B, P + N0, Dt) -> xf_out
@@ -297,6 +320,10 @@ int mdm_debug_stamps(uint64_t* out16);
  * enable during hipGraph capture).  mdm_probe_read synchronises the events and returns the number of launches recorded
  * since the last enable, writing up to `cap` durations (microseconds) and row counts. */
 int mdm_probe_enable(int32_t enable);
+/* Test aid: while buf is non-NULL, mdm_denoiser_forward copies the router's decisions into it, laid out like
+ * forced_routing: int32 [2L][2 branches][B*S_layer (padded to B*T)][2] (mdm_block_forward(MDM_BLOCK_MOE): one layer's worth).
+ * Used to count routing flips against the oracle; pass NULL to switch it off. */
+int mdm_route_dump(int32_t* buf);
 int mdm_probe_read(float* us, int32_t* rows, int32_t cap);
 
 const char* mdm_version(void);

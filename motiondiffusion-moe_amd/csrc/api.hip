@@ -20,6 +20,18 @@ __global__ void pack_bf16_kernel(const float* __restrict__ src, int64_t ld_src, 
   }
 }
 
+__global__ void pack_f16_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows, int64_t K,
+                                uint16_t* __restrict__ dst, int64_t ld_dst) {
+  const int64_t pairs_per_row = ld_dst >> 1;
+  const int64_t total = rows * pairs_per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / pairs_per_row, k = (i - r * pairs_per_row) * 2;
+    const float a = k < K ? src[r * ld_src + k] : 0.f;
+    const float b = k + 1 < K ? src[r * ld_src + k + 1] : 0.f;
+    *(uint32_t*)(dst + r * ld_dst + k) = pack_f16(a, b);
+  }
+}
+
 }  // namespace
 }  // namespace mdm
 
@@ -55,6 +67,17 @@ int mdm_pack_bf16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uin
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(mdm::pack_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, K, hi,
                      lo, ld_dst);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int mdm_pack_f16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* dst, int64_t ld_dst, void* stream) {
+  if (!src || !dst || rows < 0 || K <= 0 || ld_dst < K || (ld_dst & 31)) return MDM_ERR_ARG;
+  if (rows == 0) return MDM_OK;
+  const int64_t total = rows * (ld_dst >> 1);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(mdm::pack_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, K, dst, ld_dst);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
         }
         v = v * (cv[j] * rs[r]) + g.r1_scale * q1[r][j] + q2[r][j];
         if (C) C[(int64_t)m * g.ldc + n] = v;
-        if (C16) C16[(int64_t)m * g.ldc + n] = (uint16_t)(pack_bf16(v, 0.f) & 0xffff);
+        if (C16) C16[(int64_t)m * g.ldc + n] = (uint16_t)(pack_h16(g.h16, v, 0.f) & 0xffff);
       }
     }
   }
@@ -353,7 +353,10 @@ int launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-int gemm(const GemmArgs& a, hipStream_t stream) {
+int gemm(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
+  if (a.precision == 2) a.precision = 1, a.h16 = MDM_H16_F16;  // "2" = single pass with fp16 operands
+  if (a.h16 != MDM_H16_F16) a.h16 = MDM_H16_BF16;
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return MDM_OK;
   if (a.K <= 0 || !a.A.p || !a.W.p || (!a.C && !a.C16)) return MDM_ERR_ARG;
   if (a.A.kind == OP_BF16_ROW) return gemm_bf16(a, stream);  // bf16 activations: throughput kernel (gemm2.hip)

@@ -14,8 +14,6 @@ namespace {
 
 constexpr int BN = 128, NT = 256;
 
-typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
-
 __device__ __forceinline__ void glds16(const void* g, uint8_t* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -51,8 +49,9 @@ __device__ __forceinline__ int chunk_logical(int row, int phys) {
   return (phys - 2 * (row >> 2)) & 3;
 }
 
-template <int BM, int BK, int NSTAGE, int ACT>
+template <typename HT, int BM, int BK, int NSTAGE, int ACT>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
+  typedef typename HT::frag_t frag_t;
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   constexpr int ROWB = 2 * BK;             // bytes per LDS row
   constexpr int TILE_A = BM * ROWB, TILE_W = BN * ROWB;  // bytes per operand per stage
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);  // D = W A^T: (n, m)
+          acc[i][j] = HT::mfma16(b[j], a[i], acc[i][j]);  // D = W A^T: (n, m)
     }
   }
 
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       v[0] += g.r1_scale * q1[k][0] + q2[k][0], v[1] += g.r1_scale * q1[k][1] + q2[k][1];
       v[2] += g.r1_scale * q1[k][2] + q2[k][2], v[3] += g.r1_scale * q1[k][3] + q2[k][3];
       if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;
-      if (C16) *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      if (C16) *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
     }
   } else {
     for (int k = 0; k < NR; ++k) {  // ragged N edge / unaligned leading dimensions: element-wise
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
         if (R1) x += g.r1_scale * R1[mr * g.ldr1 + n + r];
         if (R2) x += R2[(int64_t)m * g.ldr2 + n + r];
         if (C) C[(int64_t)m * g.ldc + n + r] = x;
-        if (C16) C16[(int64_t)m * g.ldc + n + r] = (uint16_t)(pack_bf16(x, 0.f) & 0xffff);
+        if (C16) C16[(int64_t)m * g.ldc + n + r] = (uint16_t)(HT::pack(x, 0.f) & 0xffff);
       }
     }
   }
@@ -331,12 +330,12 @@ bool gemm_bf16_eligible(const GemmArgs& a) {
          ((((uintptr_t)a.A.p) | ((uintptr_t)a.W.p)) & 15) == 0 && a.A.rpg == 0;
 }
 
-template <int BM, int BK, int NS, int ACT>
+template <typename HT, int BM, int BK, int NS, int ACT>
 static int launch_bf16_act(const GemmArgs& a, hipStream_t stream) {
   constexpr int smem = NS * (BM + BN) * 2 * BK;
   static bool attr_set = false;
   if (smem > 65536 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BK, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<HT, BM, BK, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr_set = true;
@@ -344,20 +343,25 @@ static int launch_bf16_act(const GemmArgs& a, hipStream_t stream) {
   const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
   const int tn = (a.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BK, NS, ACT>), grid, dim3(NT), smem, stream, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<HT, BM, BK, NS, ACT>), grid, dim3(NT), smem, stream, a);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
 
-template <int BM, int BK, int NS>
-static int launch_bf16(const GemmArgs& a, hipStream_t stream) {
+template <typename HT, int BM, int BK, int NS>
+static int launch_bf16_h(const GemmArgs& a, hipStream_t stream) {
   switch (a.act) {
-    case ACT_NONE: return launch_bf16_act<BM, BK, NS, ACT_NONE>(a, stream);
-    case ACT_GELU: return launch_bf16_act<BM, BK, NS, ACT_GELU>(a, stream);
-    case ACT_SILU: return launch_bf16_act<BM, BK, NS, ACT_SILU>(a, stream);
-    case ACT_FEAT: return launch_bf16_act<BM, BK, NS, ACT_FEAT>(a, stream);
+    case ACT_NONE: return launch_bf16_act<HT, BM, BK, NS, ACT_NONE>(a, stream);
+    case ACT_GELU: return launch_bf16_act<HT, BM, BK, NS, ACT_GELU>(a, stream);
+    case ACT_SILU: return launch_bf16_act<HT, BM, BK, NS, ACT_SILU>(a, stream);
+    case ACT_FEAT: return launch_bf16_act<HT, BM, BK, NS, ACT_FEAT>(a, stream);
     default: return MDM_ERR_ARG;
   }
+}
+// h16 == MDM_H16_F16: the 16-bit operands (and the optional 16-bit output copy) are IEEE fp16 instead of bf16
+template <int BM, int BK, int NS>
+static int launch_bf16(const GemmArgs& a, hipStream_t stream) {
+  return a.h16 == MDM_H16_F16 ? launch_bf16_h<HF, BM, BK, NS>(a, stream) : launch_bf16_h<HB, BM, BK, NS>(a, stream);
 }
 
 int gemm_bf16(const GemmArgs& a, hipStream_t stream) {

@@ -14,15 +14,14 @@ namespace {
 constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
 constexpr int ROWB = 2 * BK, TILE_B = BM * ROWB, STAGE_B = 2 * TILE_B;  // 32 KiB per operand per stage
 
-typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
-
 __device__ __forceinline__ void glds16(const void* g, uint8_t* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int ACT>
+template <typename HT, int ACT>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_256_kernel(const GemmArgs g) {
+  typedef typename HT::frag_t frag_t;
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_256_kernel(const GemmArgs g) 
         const int ra = wm * 128 + i * 16 + frow;
         const frag_t a = *(const frag_t*)(sa + ra * ROWB + (((ks * 4 + fq) ^ (ra & 7)) << 4));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = HT::mfma16(b[j], a, acc[i][j]);
       }
     }
   }
@@ -169,24 +168,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_256_kernel(const GemmArgs g) 
         v[0] += g.r1_scale * q1[k][0] + q2[k][0], v[1] += g.r1_scale * q1[k][1] + q2[k][1];
         v[2] += g.r1_scale * q1[k][2] + q2[k][2], v[3] += g.r1_scale * q1[k][3] + q2[k][3];
         if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;
-        if (C16) *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+        if (C16) *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
       }
     }
   }
 }
 
-template <int ACT>
+template <typename HT, int ACT>
 int launch256(const GemmArgs& a, hipStream_t stream) {
   constexpr int smem = 2 * STAGE_B;  // 128 KiB
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+    if (hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<HT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
         hipSuccess)
       return MDM_ERR_LAUNCH;
     attr = true;
   }
   const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
-  hipLaunchKernelGGL((gemm_bf16_256_kernel<ACT>), dim3((unsigned)(tm * (a.N / BN))), dim3(NT), smem, stream, a);
+  hipLaunchKernelGGL((gemm_bf16_256_kernel<HT, ACT>), dim3((unsigned)(tm * (a.N / BN))), dim3(NT), smem, stream, a);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
@@ -207,10 +206,11 @@ bool gemm_bf16_256_eligible(const GemmArgs& a) {
 int gemm_bf16_256(const GemmArgs& a, hipStream_t stream) {
   if (!gemm_bf16_256_eligible(a)) return MDM_ERR_UNSUPPORTED;
   if (!a.C && !a.C16) return MDM_ERR_ARG;
+  const bool f16 = a.h16 == MDM_H16_F16;
   switch (a.act) {
-    case ACT_NONE: return launch256<ACT_NONE>(a, stream);
-    case ACT_GELU: return launch256<ACT_GELU>(a, stream);
-    default: return launch256<ACT_SILU>(a, stream);
+    case ACT_NONE: return f16 ? launch256<HF, ACT_NONE>(a, stream) : launch256<HB, ACT_NONE>(a, stream);
+    case ACT_GELU: return f16 ? launch256<HF, ACT_GELU>(a, stream) : launch256<HB, ACT_GELU>(a, stream);
+    default: return f16 ? launch256<HF, ACT_SILU>(a, stream) : launch256<HB, ACT_SILU>(a, stream);
   }
 }
 

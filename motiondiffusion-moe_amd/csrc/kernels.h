@@ -14,7 +14,7 @@ struct MoeGateParams {
   const float* gate_w[2];  // (E, D) fp32
   const float* gate_b[2];  // (E)
   void* hn;                // (2, M, D) out: LN_b(x), fp32 or bf16
-  int hn_bf16;
+  int hn_bf16;             // 0 = fp32, else the 16-bit format code (MDM_H16_*)
   int* top_idx;            // (2, M, 2)
   float* top_val;          // (2, M, 2)
   int* hist;               // [1024][32] per-block partial histograms (no atomics, no memset)
@@ -24,13 +24,14 @@ struct MoeGateParams {
   const int* forced_idx;   // optional (2, M, 2) injected routing (tests)
 };
 
-// y1/y2/out: fp32 tensors, or bf16 (uint16_t) when the matching *_bf flag is set
-// x_bf: the input rows are bf16 (throughput mode tensors whose only consumer is this LayerNorm)
+// y1/y2/out: fp32 tensors, or 16-bit (uint16_t) when the matching *_bf flag is non-zero; the flag IS the format code
+// (MDM_H16_BF16 = 1, MDM_H16_F16 = 2).  x_bf: the input rows are 16-bit in that format (tensors whose only consumer is
+// this LayerNorm)
 int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1, void* y1, int y1_bf, const float* w2,
              const float* b2, void* y2, int y2_bf, hipStream_t s, int x_bf = 0);
 int style_in(const float* x, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw,
              const float* sb, const float* sc, const int* pos4, int x_bf, void* out, int out_bf, hipStream_t s);
-int to_bf16(const float* src, int64_t n, uint16_t* dst, hipStream_t s);
+int to_bf16(const float* src, int64_t n, uint16_t* dst, int h16, hipStream_t s);  // h16: MDM_H16_BF16 / MDM_H16_F16
 int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, int* goff, int* cursor, int* perm,
               float* rowscale, int* pos4, hipStream_t s);
 int head_norm(float* qkv, int64_t M, int H, int dh, const float* w, const float* b, hipStream_t s);
@@ -39,30 +40,33 @@ int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const f
 int head_softmax(float* q, int64_t units, int dh, hipStream_t s);
 // fused Performer attention core (perf_attn.hip): qkv fp32 (M,3D) -> LN_dh(num/den) as bf16 (M,D)
 bool perf_attn_supported(int dh, int S);
-int perf_attn(const void* qkv, int qkv_bf16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
+int perf_attn(const void* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s);
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
 // fused text cross-attention cores (xattn.hip), head_dim 128
 bool xattn_supported(int dh, int N);
-int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
-            float* out32, hipStream_t s);
-int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
-              hipStream_t s);
+int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
+            float* out32, int h16, hipStream_t s);
+int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
+              int h16, hipStream_t s);
 // sdfold.hip: text cross-attention with folded projections + the following LayerNorm, one launch
 bool sd_fold_supported(int D, int H, int N);
 int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const uint16_t* vfold, const float* bout,
             const float* ln_w, const float* ln_b, int B, int S, int D, int H, int N, float* out32, uint16_t* out16,
-            hipStream_t s);
+            int h16, hipStream_t s);
 int col_softmax(float* k, int B, int N, int D, hipStream_t s);
 int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s);
 int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s);
 int gated_mix_gather(const float* table, const int64_t* ts, int steps, const float* x, int B, int D, float* out,
-                     uint16_t* out16, hipStream_t s);
+                     uint16_t* out16, int h16, hipStream_t s);
 int text_assemble(const float* pp, const float* ph, int B, int N0, int P, int Dt, float* xf_out, float* xf_proj,
                   hipStream_t s);
 // motion_post.hip: 263-d HumanML3D rows -> (T, J, 3) joints, optional temporal gaussian filter (wts[0..radius])
 int motion_post(const float* x, const int* len, const float* mean, const float* sd, int B, int T, int feats, int J,
                 int radius, const double* wts, float* raw, float* out, hipStream_t s);
+// noise.hip: Philox4x32-10 + Box-Muller, keyed on (seed, global sample, stream, element)
+int philox_normal(float* out, int64_t per_sample, int nsamples, int64_t sample0, uint64_t seed, const int* stream_dev,
+                  int stream_imm, hipStream_t s);
 int iota_i64(int64_t* dst, int64_t n, int64_t start, hipStream_t s);
 int xattn_gate(const float* gate, const float* ag, int D, float* out, hipStream_t s);
 int halve_lengths(const int* len, int B, int* out, hipStream_t s);

@@ -34,6 +34,48 @@ __device__ __forceinline__ void split_bf16(float a, float b, uint32_t& hi, uint3
   lo = pack_bf16(a - bf16_lo_f32(hi), b - bf16_hi_f32(hi));
 }
 
+// ---- the 16-bit operand format of the throughput kernels -----------------------------------------------------------
+// Every single-pass MFMA kernel is templated on one of these two traits: bf16 (8 significand bits, fp32 range) or IEEE
+// fp16 (11 significand bits, |x| <= 65504).  Both MFMA forms run at the same rate on gfx950 and both conversions are
+// one packed instruction, so fp16 buys 8x smaller operand rounding for free wherever the value range is known (LayerNorm
+// outputs, GELU hidden units, softmax weights, weights of trained Linears).  Host-side format codes: MDM_H16_*.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2_t r = __builtin_convertvector(v, f16x2_t);  // v_cvt_pk_f16_f32 (round to nearest even)
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float f16_lo_f32(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p & 0xffffu)); }
+__device__ __forceinline__ float f16_hi_f32(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p >> 16)); }
+struct HB {  // bf16
+  typedef bf16x8_t frag_t;
+  static constexpr int FMT = 1;
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return pack_bf16(a, b); }
+  static __device__ __forceinline__ float lo(uint32_t p) { return bf16_lo_f32(p); }
+  static __device__ __forceinline__ float hi(uint32_t p) { return bf16_hi_f32(p); }
+  static __device__ __forceinline__ float one(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+  static __device__ __forceinline__ f32x4 mfma16(frag_t a, frag_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct HF {  // fp16
+  typedef f16x8_t frag_t;
+  static constexpr int FMT = 2;
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return pack_f16(a, b); }
+  static __device__ __forceinline__ float lo(uint32_t p) { return f16_lo_f32(p); }
+  static __device__ __forceinline__ float hi(uint32_t p) { return f16_hi_f32(p); }
+  static __device__ __forceinline__ float one(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+  static __device__ __forceinline__ f32x4 mfma16(frag_t a, frag_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+// run-time format (row-wise kernels, generic epilogues): fmt 1 = bf16, 2 = fp16
+__device__ __forceinline__ uint32_t pack_h16(int fmt, float a, float b) { return fmt == 2 ? pack_f16(a, b) : pack_bf16(a, b); }
+__device__ __forceinline__ float h16_lo_f32(int fmt, uint32_t p) { return fmt == 2 ? f16_lo_f32(p) : bf16_lo_f32(p); }
+__device__ __forceinline__ float h16_hi_f32(int fmt, uint32_t p) { return fmt == 2 ? f16_hi_f32(p) : bf16_hi_f32(p); }
+
 // erf(x) as the odd rational P(x^2) x / Q(x^2) on [-4, 4] (|erf| = 1 beyond to fp32 precision): max abs error
 // 3.8e-7 against libm over [-6, 6] (checked in tests/test_host_logic.py), ~16 instructions, no branches.  The
 // libm erff inlined 64x per thread dominated the GEMM epilogues.

@@ -27,14 +27,14 @@ constexpr int XT_B = BM * 128, W1T_B = FC * 128;  // phase-1 tiles: 128-B rows (
 constexpr int STAGE_B = XT_B + W1T_B;         // 49152; a phase-2 stage (W2 slab [512][32 k], 32 KiB) uses part of it
 constexpr int NST = 2;
 
-typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
-
 __device__ __forceinline__ void glds16(const void* g, uint8_t* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+template <typename HT>
 __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
+  typedef typename HT::frag_t frag_t;
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   uint8_t* hc = smem;
   uint8_t* ring = smem + HC_B;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
             const int rb = wn * 64 + j * 16 + frow;
             const frag_t b = *(const frag_t*)(s + XT_B + rb * 128 + (((ks * 4 + fq) ^ (rb & 7)) << 4));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], h[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) h[i][j] = HT::mfma16(b, a[i], h[i][j]);
           }
         }
       }
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
           const float v0 = g01[0], v1 = g01[1], v2 = g23[0], v3 = g23[1];
           // hidden chunk image: 512-B rows, 16-B chunk index (f >> 3) swizzled by (m & 15); 8-B half (f >> 2) & 1
           *(uint2*)(hc + m * 512 + (((f >> 3) ^ (m & 15)) << 4) + ((f >> 2) & 1) * 8) =
-              make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+              make_uint2(HT::pack(v0, v1), HT::pack(v2, v3));
         }
       }
     }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
         const int n = wn * 128 + j * 16 + frow;
         const frag_t b = *(const frag_t*)(s + n * 64 + (((fq + 2 * (n >> 2)) & 3) << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], y[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) y[i][j] = HT::mfma16(b, a[i], y[i][j]);
       }
     }
   }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
         v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
       }
       if (g.C) *(f32x4*)(g.C + (int64_t)m * g.ldc + n) = v;
-      if (g.C16) *(uint2*)(g.C16 + (int64_t)m * g.ldc + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      if (g.C16) *(uint2*)(g.C16 + (int64_t)m * g.ldc + n) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
     }
   }
 }
@@ -255,12 +255,17 @@ int fused_mlp(const MdmMlpDesc& a, hipStream_t stream) {
   constexpr int smem = HC_B + NST * STAGE_B;  // 163840
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)fused_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)fused_mlp_kernel<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)fused_mlp_kernel<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr = true;
   }
   const int tiles = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
-  hipLaunchKernelGGL(fused_mlp_kernel, dim3(tiles), dim3(NT), smem, stream, a);
+  if (a.h16 == MDM_H16_F16) {
+    hipLaunchKernelGGL(fused_mlp_kernel<HF>, dim3(tiles), dim3(NT), smem, stream, a);
+  } else {
+    hipLaunchKernelGGL(fused_mlp_kernel<HB>, dim3(tiles), dim3(NT), smem, stream, a);
+  }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

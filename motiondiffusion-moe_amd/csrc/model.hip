@@ -24,6 +24,7 @@ struct Probe {
   bool made = false;
 };
 Probe g_probe;
+int32_t* g_route_dump = nullptr;  // mdm_route_dump: where the router's top-2 indices of every layer are copied (tests)
 
 struct Bump {  // carve the caller's workspace; with base == nullptr it only measures
   uint8_t* base;
@@ -88,8 +89,10 @@ Work carve(const MdmModel& m, int B, int T, int N, void* ws) {
 struct Ctx {
   const MdmModel* m;
   hipStream_t s;
-  int prec;
-  bool bf;          // throughput mode (precision 1): GEMM-only tensors are kept in bf16
+  int prec;         // GEMMs with fp32 activations: 1 = single bf16 pass, 3 = bf16x3
+  bool bf;          // throughput modes (precision 1 / 2): GEMM-only tensors are kept in 16 bits
+  int h16;          // the 16-bit format of this run: MDM_H16_BF16 (precision 1, 3) or MDM_H16_F16 (precision 2, 4)
+  bool mix;         // precision 4: fp32-grade flow, but expert MLPs + the 4x FFN run as ONE fp16 pass on 16-bit operands
   int B, S, N;      // batch, frames at this scale, text tokens
   int64_t M;        // B*S
   const int* len;   // lengths at this scale
@@ -97,6 +100,33 @@ struct Ctx {
 };
 
 inline Operand packed(const MdmPacked& p) { return op_bf16(p.hi, p.lo, p.ld); }
+
+// bf16 activation plumbing needs every GEMM K (D, 2D, 4D, F) to be a multiple of the 64-wide LDS-DMA k-tile
+bool use_bf16_acts(const MdmModel* m, int precision) {
+  return (precision == MDM_PREC_BF16 || precision == MDM_PREC_F16) && m->D % 64 == 0 && m->F % 64 == 0;
+}
+// precision (include/mdm_hip.h: MDM_PREC_*) -> how this run computes; false = unsupported combination
+bool set_precision(Ctx& c, const MdmModel* m, int precision) {
+  c.mix = false, c.bf = false, c.h16 = MDM_H16_BF16;
+  switch (precision) {
+    case MDM_PREC_BF16: c.prec = 1, c.bf = use_bf16_acts(m, precision); return true;
+    case MDM_PREC_F16:  // fp16 weight planes are only readable by the 16-bit-activation kernels
+      c.prec = 1, c.bf = use_bf16_acts(m, precision), c.h16 = MDM_H16_F16;
+      return c.bf;
+    case MDM_PREC_X3: c.prec = 3; return true;
+    case MDM_PREC_MIXED:
+      c.prec = 3, c.h16 = MDM_H16_F16, c.mix = m->D % 64 == 0 && m->F % 64 == 0;
+      return c.mix;
+    default: return false;
+  }
+}
+inline GemmArgs gd(const Ctx& c) {  // GEMM descriptor defaults of this run
+  GemmArgs g = gemm_defaults(c.prec);
+  g.h16 = c.h16;
+  return g;
+}
+inline int fmt16(const Ctx& c) { return c.bf ? c.h16 : 0; }             // format code of a mode-typed tensor (0 = fp32)
+inline int fmt_mlp(const Ctx& c) { return (c.bf || c.mix) ? c.h16 : 0; }  // ... of the expert-MLP / FFN operands
 
 // a tensor that is fp32 in the fp32-grade mode and bf16 in the throughput mode, living in a float-sized buffer
 struct Act {
@@ -106,6 +136,7 @@ struct Act {
 inline Act act_of(const Ctx& c, float* buf) { return Act{buf, c.bf}; }
 inline Act act_f32(const float* buf) { return Act{(void*)buf, false}; }
 inline Act act_bf16(const uint16_t* buf) { return Act{(void*)buf, true}; }
+inline Act act_h16(const void* buf) { return Act{(void*)buf, true}; }
 
 struct LinOpts {
   int act = ACT_NONE;
@@ -119,9 +150,10 @@ struct LinOpts {
 // out32 / out16 = epilogue(A @ W^T) for a plain [M,K]x[N,K] Linear; either output may be null
 int linear(const Ctx& c, Act A, int64_t M, int K, const MdmPacked& W, const float* bias, int N, float* out32,
            uint16_t* out16, const LinOpts& o = LinOpts()) {
-  GemmArgs g = gemm_defaults(c.prec);
+  GemmArgs g = gd(c);
   if (A.bf) {
     g.A.p = A.p, g.A.ld = K, g.A.kind = OP_BF16_ROW;
+    g.precision = 1;  // 16-bit activations: one pass of the format c.h16 (the weight was packed in it)
   } else {
     g.A = op_f32((const float*)A.p, K);
   }
@@ -147,7 +179,7 @@ int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float*
                 const float* sc, float* tmp, const float* resid, float out_scale, const float* colscale, float* out,
                 uint16_t* out16 = nullptr, bool src_bf16 = false) {
   const int D = c.m->D;
-  MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, src_bf16, tmp, c.bf, c.s));
+  MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, src_bf16 ? c.h16 : 0, tmp, fmt16(c), c.s));
   LinOpts o;
   o.out_scale = out_scale, o.R1 = resid, o.colscale = colscale;
   return linear(c, act_of(c, tmp), c.M, D, st.out, st.out_b, D, out, out16, o);
@@ -167,13 +199,13 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
   }
   if (fused) {
     // throughput mode: LN/L2 -> feature maps -> KV state -> num/den -> LN in ONE kernel per (batch, head)  (:44-90)
-    MDM_TRY(perf_attn(w.qkv, 1, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, (uint16_t*)w.t4, c.s));
+    MDM_TRY(perf_attn(w.qkv, c.h16, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, (uint16_t*)w.t4, c.s));
   } else {
     // shared LN over head_dim, L2 normalise q,k                     (:44-55)
     MDM_TRY(head_norm(w.qkv, c.M, H, dh, p.hn_w, p.hn_b, c.s));
     // feature maps 0.1*exp(clamp(z P)), keys masked past length     (:58-74): rows = (token, slot<2H)
     {
-      GemmArgs g = gemm_defaults(c.prec);
+      GemmArgs g = gd(c);
       g.A = op_f32(w.qkv, dh);
       g.A.rpg = 2 * H, g.A.gstride = 3 * D;
       g.W = packed(p.feat);
@@ -185,7 +217,7 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     }
     // KV^T[b,h] (dh x m) = 0.1 * sum_t v[t] (x) kphi[t]              (:77)
     {
-      GemmArgs g = gemm_defaults(c.prec);
+      GemmArgs g = gd(c);
       g.A = op_f32_kstride(w.qkv + 2 * D, 3 * D);
       g.A.bs1 = (int64_t)c.S * 3 * D, g.A.bs2 = dh;
       g.W = op_f32_kstride(w.phi + H * mf, 2 * H * mf);
@@ -198,7 +230,7 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     }
     // num = 0.1 * qphi KV                                            (:78) -> t2 (M, D) merged heads
     {
-      GemmArgs g = gemm_defaults(c.prec);
+      GemmArgs g = gd(c);
       g.A = op_f32(w.phi, 2 * H * mf);
       g.A.bs1 = (int64_t)c.S * 2 * H * mf, g.A.bs2 = mf;
       g.W = op_f32(w.kvt, mf);
@@ -210,7 +242,7 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
       MDM_TRY(gemm(g, c.s));
     }
     // same-t denominator, divide, LN over head_dim                   (:81-90) -> t4
-    MDM_TRY(den_ln(w.t2, w.phi, c.M, H, dh, p.hn_w, p.hn_b, w.t4, c.bf, c.s));
+    MDM_TRY(den_ln(w.t2, w.phi, c.M, H, dh, p.hn_w, p.hn_b, w.t4, fmt16(c), c.s));
   }
   // proj_out: Linear -> GELU -> Linear                             (:121-126,165)
   {
@@ -233,9 +265,9 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
   const Work& w = c.w;
   const int64_t scs = (int64_t)c.B * 2 * D;
   // h = pre_norm(x) -> t1 ; local.pre_norm(h) -> t3
-  MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, 0, l.local.pre_w, l.local.pre_b, w.t3, c.bf, c.s));
+  MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, 0, l.local.pre_w, l.local.pre_b, w.t3, fmt16(c), c.s));
   MDM_TRY(performer(c, l.local, w.t1, act_of(c, w.t3), sc4 + 0 * scs, w.t5));  // local_out -> t5
-  MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
   MDM_TRY(performer(c, l.global, w.t5, act_of(c, w.t3), sc4 + 1 * scs, w.t1));  // global_out -> t1
   // skip = GELU(Lin(x)); out = post_norm(skip + 0.1 * global)      (:219-225)
   {
@@ -245,7 +277,7 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
     // error for 0.01 ms per step)
     MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.skip, l.skip_b, D, w.t3, nullptr, o));
   }
-  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, 0, next_w, next_b, next_w ? w.t2 : nullptr, c.bf, c.s);
+  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, 0, next_w, next_b, next_w ? w.t2 : nullptr, fmt16(c), c.s);
 }
 
 // GatedCrossAttention (fast_attention.py:242-272): out = x + sigmoid(gate)*sigmoid(adaptive)*style(softmax(q) A)
@@ -254,17 +286,17 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H;
   const Work& w = c.w;
-  if (!pre_normed) MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  if (!pre_normed) MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
   const bool fused = c.bf && xattn_supported(dh, 1);
   bool x16o = false;
   MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
   if (fused) {
     x16o = g_bf16_variant != 25;  // consumed by the stylization LayerNorm only: bf16
-    MDM_TRY(lin_xattn(w.t3, 1, at, c.B, c.S, H, dh, x16o ? nullptr : w.t4, x16o ? (uint16_t*)w.t4 : nullptr, c.s));  // (:248,253)
+    MDM_TRY(lin_xattn(w.t3, c.h16, at, c.B, c.S, H, dh, x16o ? nullptr : w.t4, x16o ? (uint16_t*)w.t4 : nullptr, c.h16, c.s));  // (:248,253)
   } else {
     MDM_TRY(head_softmax(w.t3, c.M * H, dh, c.s));  // softmax over head_dim (:248)
     {
-      GemmArgs g = gemm_defaults(c.prec);  // y[b,s,h,:] = q[b,s,h,:] A[b,h]  (:253), W = A^T rows
+      GemmArgs g = gd(c);  // y[b,s,h,:] = q[b,s,h,:] A[b,h]  (:253), W = A^T rows
       g.A = op_f32(w.t3, D);
       g.A.bs1 = (int64_t)c.S * D, g.A.bs2 = dh;
       g.W = op_f32(at, dh);
@@ -280,7 +312,7 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
 
 // MoEMultiBranchFFN (multi_branch.py:52-61) with SwitchMoELayer top-2 routing (switch_moe.py:44-111)
 int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, const int* forced, float* out,
-              uint16_t* out16) {
+              uint16_t* out16, int32_t* route_out = nullptr) {
   const MdmModel& m = *c.m;
   const int D = m.D, F = m.F, E = m.E;
   const Work& w = c.w;
@@ -290,8 +322,10 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     p.gate_w[b] = l.gate_w[b], p.gate_b[b] = l.gate_b[b];
     p.usage[b] = l.usage[b], p.importance[b] = l.importance[b];
   }
-  p.hn = w.hn, p.hn_bf16 = c.bf, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.uimp = w.uimp, p.forced_idx = forced;
+  p.hn = w.hn, p.hn_bf16 = fmt_mlp(c), p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.uimp = w.uimp, p.forced_idx = forced;
   MDM_TRY(moe_route(x, c.M, D, E, p, w.goff, w.cursor, w.perm, w.rowscale, w.pos4, c.s));
+  if (route_out && hipMemcpyAsync(route_out, w.top_idx, 4 * c.M * sizeof(int32_t), hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+    return MDM_ERR_LAUNCH;
   MdmMlpDesc f = {};
   f.X = (const uint16_t*)w.hn, f.ldx = D, f.gather = w.perm;
   f.M = (int)(4 * c.M), f.Din = D, f.F = F, f.Dout = D;
@@ -300,9 +334,11 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
   f.w2 = l.w2.hi, f.ldw2 = l.w2.ld, f.w2_gs = (int64_t)D * l.w2.ld, f.b2 = l.b2, f.b2_gs = D;
   f.rowscale = w.rowscale, f.r1_scale = 1.f;
   f.C = w.y2, f.ldc = D;
-  if (c.bf && g_bf16_variant != 21 && fused_mlp_supported(f)) {  // variant 21: two-GEMM chain, for A/B runs
+  f.h16 = c.h16;
+  const bool h = c.bf || c.mix;  // 16-bit expert operands
+  if (h && g_bf16_variant != 21 && fused_mlp_supported(f)) {  // variant 21: two-GEMM chain, for A/B runs
     // throughput mode: both expert GEMMs in one kernel, hidden activations stay in LDS (switch_moe.py:19-25,104-109)
-    const bool y16 = g_bf16_variant != 25;  // expert outputs stored as bf16 (what autocast does to a Linear); knob 25: fp32
+    const bool y16 = c.bf && g_bf16_variant != 25;  // expert outputs stored in 16 bits (what autocast does to a Linear); knob 25 / mixed mode: fp32
     if (y16) f.C = nullptr, f.C16 = (uint16_t*)w.y2;
     const bool pr = g_probe.on && g_probe.n < PROBE_MAX;
     if (pr && hipEventRecord(g_probe.a[g_probe.n], c.s) != hipSuccess) return MDM_ERR_LAUNCH;
@@ -314,9 +350,9 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, y16);
   }
   {
-    GemmArgs g = gemm_defaults(c.prec);  // hidden = GELU(LN_b(x)[routed rows] W1_e^T + b1_e)
-    if (c.bf) {
-      g.A.p = w.hn, g.A.ld = D, g.A.kind = OP_BF16_ROW;
+    GemmArgs g = gd(c);  // hidden = GELU(LN_b(x)[routed rows] W1_e^T + b1_e)
+    if (h) {
+      g.A.p = w.hn, g.A.ld = D, g.A.kind = OP_BF16_ROW, g.precision = 1;
     } else {
       g.A = op_f32(w.hn, D);
     }
@@ -327,13 +363,13 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     g.M = (int)(4 * c.M), g.N = F, g.K = D;
     g.bias = l.b1, g.bias_bs = F;
     g.act = ACT_GELU;
-    g.C = c.bf ? nullptr : w.hid, g.C16 = c.bf ? (uint16_t*)w.hid : nullptr, g.ldc = F;
+    g.C = h ? nullptr : w.hid, g.C16 = h ? (uint16_t*)w.hid : nullptr, g.ldc = F;
     MDM_TRY(gemm(g, c.s));
   }
   {
-    GemmArgs g = gemm_defaults(c.prec);  // y2[pos] = prob[pos] * (hidden W2_e^T + b2_e)      (switch_moe.py:108-109)
-    if (c.bf) {
-      g.A.p = w.hid, g.A.ld = F, g.A.kind = OP_BF16_ROW;
+    GemmArgs g = gd(c);  // y2[pos] = prob[pos] * (hidden W2_e^T + b2_e)      (switch_moe.py:108-109)
+    if (h) {
+      g.A.p = w.hid, g.A.ld = F, g.A.kind = OP_BF16_ROW, g.precision = 1;
     } else {
       g.A = op_f32(w.hid, F);
     }
@@ -365,7 +401,7 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
   if (c.bf && fold.kfold && g_bf16_variant != 22 && sd_fold_supported(D, H, N)) {
     // throughput mode: query GEMM + attention core + output GEMM + LayerNorm in one launch (csrc/sdfold.hip)
     MDM_TRY(sd_fold(x16, fold.kfold, fold.cb, fold.vfold, l.sd_out_b, l.sd_ln_w, l.sd_ln_b, c.B, c.S, D, H, N, w.t3,
-                    (uint16_t*)w.t4, c.s));
+                    (uint16_t*)w.t4, c.h16, c.s));
     LinOpts o1;
     o1.act = ACT_GELU;
     MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, w.f1, o1));
@@ -381,10 +417,10 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
                    fz ? (uint16_t*)w.t1 : nullptr, o));
   }
   if (c.bf && xattn_supported(dh, N)) {
-    MDM_TRY(sd_attn(w.t1, 1, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.s));  // scores, softmax, PV fused
+    MDM_TRY(sd_attn(w.t1, c.h16, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.h16, c.s));  // scores, softmax, PV fused
   } else {
     {
-      GemmArgs g = gemm_defaults(c.prec);  // scores[b,h,s,n] = q . k
+      GemmArgs g = gd(c);  // scores[b,h,s,n] = q . k
       g.A = op_f32(w.t1, D);
       g.A.bs1 = (int64_t)c.S * D, g.A.bs2 = dh;
       g.W = op_f32(kc, D);
@@ -396,7 +432,7 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
     }
     MDM_TRY(row_softmax(w.scr, c.M * H, N, c.s));
     {
-      GemmArgs g = gemm_defaults(c.prec);  // o[b,s,h,:] = p v
+      GemmArgs g = gd(c);  // o[b,s,h,:] = p v
       g.A = op_f32(w.scr, N);
       g.A.bs1 = (int64_t)H * c.S * N, g.A.bs2 = (int64_t)c.S * N;
       g.W = op_f32_kstride(vc, D);
@@ -409,15 +445,17 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
     }
   }
   MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.sd_out, l.sd_out_b, D, w.t3, nullptr));
-  MDM_TRY(ln_chain(w.t3, c.M, D, l.sd_ln_w, l.sd_ln_b, w.t4, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  // the 4x FFN (LayerNorm -> Linear -> GELU -> Linear): 16-bit operands in the throughput AND the mixed mode
+  const bool h = c.bf || c.mix;
+  MDM_TRY(ln_chain(w.t3, c.M, D, l.sd_ln_w, l.sd_ln_b, w.t4, fmt_mlp(c), nullptr, nullptr, nullptr, 0, c.s));
   {
     LinOpts o;
     o.act = ACT_GELU;
-    MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, w.f1, o));
+    MDM_TRY(linear(c, Act{w.t4, h}, c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, h ? nullptr : w.f1, h ? (uint16_t*)w.f1 : nullptr, o));
   }
   LinOpts o;  // x + (o + ffn(o))
   o.R1 = x, o.R2 = w.t3;
-  return linear(c, act_of(c, w.f1), c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, out16, o);
+  return linear(c, Act{w.f1, h}, c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, out16, o);
 }
 
 const float* tc_at(const MdmModel& m, const MdmTextCache& tc, int layer) {
@@ -442,7 +480,7 @@ SdFold tc_fold(const MdmModel& m, const MdmTextCache& tc, int layer) {
 
 // one MoEExtendedDecoderLayer (transformer.py:55-64): x (+ bf16 shadow x16) is updated in place, (y, y16) is scratch
 int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, float* x, uint16_t* x16, float* y, uint16_t* y16,
-                  const float* sc4, const int* forced, float* trace) {
+                  const float* sc4, const int* forced, float* trace, int32_t* route_out = nullptr) {
   const MdmModel& m = *c.m;
   const MdmLayer& l = m.layers[layer];
   const int64_t scs = (int64_t)c.B * 2 * m.D, n = c.M * m.D;
@@ -456,7 +494,7 @@ int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, float* x, uin
   MDM_TRY(dump(0, y));
   MDM_TRY(cross_block(c, l, tc_at(m, tc, layer), y, sc4 + 2 * scs, x, true));
   MDM_TRY(dump(1, x));
-  MDM_TRY(moe_block(c, l, x, sc4 + 3 * scs, forced, y, y16));
+  MDM_TRY(moe_block(c, l, x, sc4 + 3 * scs, forced, y, y16, route_out));
   MDM_TRY(dump(2, y));
   MDM_TRY(sdcross_block(c, l, tc_k(m, tc, layer), tc_v(m, tc, layer), y, y16, x, x16, tc_fold(m, tc, layer)));
   return dump(3, x);
@@ -503,13 +541,13 @@ int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj
   float* mix = w.s_b;
   if (sc_cache && sc_cache->time_table && sc_cache->gx) {
     MDM_TRY(gated_mix_gather(sc_cache->time_table, timesteps, sc_cache->steps, sc_cache->gx, B, D, c.bf ? nullptr : mix,
-                             c.bf ? (uint16_t*)mix : nullptr, c.s));
+                             c.bf ? (uint16_t*)mix : nullptr, c.h16, c.s));
   } else {
     MDM_TRY(stem_time_branch(c, timesteps, B, w.s_b));
     MDM_TRY(stem_text_branch(c, xf_proj, B, w.s_a));
     MDM_TRY(gated_mix(w.s_b, w.s_a, (int64_t)B * D, w.s_c, c.s));
     if (c.bf) {
-      MDM_TRY(to_bf16(w.s_c, (int64_t)B * D, (uint16_t*)w.s_b, c.s));
+      MDM_TRY(to_bf16(w.s_c, (int64_t)B * D, (uint16_t*)w.s_b, c.h16, c.s));
     } else {
       mix = w.s_c;
     }
@@ -520,9 +558,9 @@ int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj
   // all 8L blocks at once: e1 = SiLU(emb Weph^T + beph) [B, 8L*Te]; sc[j] = e1[:, j] W1_j^T + b1_j [8L, B, 2D]
   MDM_TRY(linear_to_act(c, c.bf ? act_bf16((uint16_t*)w.s_c) : act_f32(emb), B, D, m.style_eph, m.style_eph_b, nblk * Te,
                         w.e1, silu_o));
-  GemmArgs g = gemm_defaults(c.prec);
+  GemmArgs g = gd(c);
   if (c.bf) {
-    g.A.p = w.e1, g.A.ld = (int64_t)nblk * Te, g.A.kind = OP_BF16_ROW;
+    g.A.p = w.e1, g.A.ld = (int64_t)nblk * Te, g.A.kind = OP_BF16_ROW, g.precision = 1;
   } else {
     g.A = op_f32(w.e1, (int64_t)nblk * Te);
   }
@@ -535,9 +573,6 @@ int stem_embeddings(const Ctx& c, const int64_t* timesteps, const float* xf_proj
   g.C = sc_out, g.ldc = 2 * D, g.c_bs1 = (int64_t)B * 2 * D;
   return gemm(g, c.s);
 }
-
-// bf16 activation plumbing needs every GEMM K (D, 2D, 4D, F) to be a multiple of the 64-wide LDS-DMA k-tile
-bool use_bf16_acts(const MdmModel* m, int precision) { return precision == 1 && m->D % 64 == 0 && m->F % 64 == 0; }
 
 int check_model(const MdmModel* m) {
   if (!m || !m->layers || m->D <= 0 || m->H <= 0 || m->D % m->H || m->L <= 0 || m->E < 2 || m->E > 16) return MDM_ERR_ARG;
@@ -565,7 +600,10 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
   if (!xf_out || !tc || !tc->lin_at || !tc->sd_k || !tc->sd_v || tc->B <= 0 || tc->N <= 0 || tc->N > 128 || !ws)
     return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = tc->B, c.N = tc->N;
+  // computed once per caption batch, never per step: always the bf16x3 arithmetic (its weights are packed bf16 hi + lo in
+  // every mode); `precision` only selects the 16-bit format of the folded K' / V' images
+  c.m = m, c.s = (hipStream_t)stream, c.prec = 3, c.bf = false, c.mix = false, c.B = tc->B, c.N = tc->N;
+  c.h16 = (precision == MDM_PREC_F16 || precision == MDM_PREC_MIXED) ? MDM_H16_F16 : MDM_H16_BF16;
   c.w = carve(*m, tc->B, 2, tc->N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const int D = m->D, H = m->H, dh = D / H, N = tc->N, B = tc->B;
@@ -576,7 +614,7 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
     MDM_TRY(linear(c, act_f32(c.w.tn), BN, m->Dt, l.ca_k, l.ca_k_b, D, c.w.kb, nullptr));
     MDM_TRY(col_softmax(c.w.kb, B, N, D, c.s));  // softmax over text tokens (fast_attention.py:249)
     MDM_TRY(linear(c, act_f32(c.w.tn), BN, m->Dt, l.ca_v, l.ca_v_b, D, c.w.vb, nullptr));
-    GemmArgs g = gemm_defaults(precision);  // A^T[b,h][l][d] = sum_n v[n,l] k[n,d]   (fast_attention.py:252)
+    GemmArgs g = gemm_defaults(3);  // A^T[b,h][l][d] = sum_n v[n,l] k[n,d]   (fast_attention.py:252)
     g.A = op_f32_kstride(c.w.vb, D);
     g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
     g.W = op_f32_kstride(c.w.kb, D);
@@ -603,6 +641,7 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
         g.M = N, g.N = D, g.K = dh;
         g.batch = B * H, g.nb2 = H;
         g.alpha = scale;
+        g.h16 = c.h16;
         g.C16 = (uint16_t*)f.kfold, g.ldc = D, g.c_bs1 = (int64_t)128 * D, g.c_bs2 = (int64_t)N * D;
         MDM_TRY(gemm(g, c.s));
       }
@@ -626,6 +665,7 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
         g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
         g.M = D, g.N = N, g.K = dh;
         g.batch = B * H, g.nb2 = H;
+        g.h16 = c.h16;
         g.C16 = (uint16_t*)f.vfold, g.ldc = 128, g.c_bs1 = (int64_t)D * 128, g.c_bs2 = N;
         MDM_TRY(gemm(g, c.s));
       }
@@ -639,7 +679,8 @@ int mdm_stem_embeddings(const MdmModel* m, const int64_t* timesteps, const float
   MDM_TRY(check_model(m));
   if (!timesteps || !xf_proj || !sc_out || !ws || B <= 0) return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B;
+  c.m = m, c.s = (hipStream_t)stream, c.B = B;
+  if (!set_precision(c, m, precision)) return MDM_ERR_UNSUPPORTED;
   c.w = carve(*m, B, 2, 1, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   return stem_embeddings(c, timesteps, xf_proj, nullptr, emb_out, sc_out);
@@ -652,7 +693,7 @@ int mdm_stem_cache_build(const MdmModel* m, int32_t steps, float* time_table, co
   constexpr int CH = 128;
   Ctx c = {};
   // tabulated in the fp32-grade arithmetic regardless of the run mode: it is computed once per loop
-  c.m = m, c.s = (hipStream_t)stream, c.prec = 3, c.bf = false, c.B = CH;
+  c.m = m, c.s = (hipStream_t)stream, c.prec = 3, c.bf = false, c.mix = false, c.h16 = MDM_H16_BF16, c.B = CH;
   (void)precision;
   c.w = carve(*m, CH, 2, 1, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
@@ -680,7 +721,8 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
   if (T % 2 || T > m->num_frames) return MDM_ERR_ARG;  // odd T breaks the U-shape (transformer.py:223-224,353)
   if (tc->B != B) return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B, c.N = tc->N;
+  c.m = m, c.s = (hipStream_t)stream, c.B = B, c.N = tc->N;
+  if (!set_precision(c, m, precision)) return MDM_ERR_UNSUPPORTED;
   c.w = carve(*m, B, T, tc->N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const Work& w = c.w;
@@ -702,7 +744,8 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
   for (int i = 0; i < L; ++i) {  // coarse scale blocks, in place on xa (xb = scratch)      (:343-344)
     const int32_t* fr = forced_routing ? forced_routing + (int64_t)i * 4 * Mfull : nullptr;
     float* tr = trace ? trace + (int64_t)i * 4 * Mfull * D : nullptr;
-    MDM_TRY(decoder_layer(c, i, *tc, w.xa, w.xa16, w.xb, w.xb16, w.sc + i * scl, fr, tr));
+    int32_t* rd = g_route_dump ? g_route_dump + (int64_t)i * 4 * Mfull : nullptr;
+    MDM_TRY(decoder_layer(c, i, *tc, w.xa, w.xa16, w.xb, w.xb16, w.sc + i * scl, fr, tr, rd));
   }
   // ConvTranspose1d(k=2,s=2) == Linear D -> 2D per coarse frame, rows (B*T/2, 2D) == (B*T, D); + skip h  (:347-353)
   {
@@ -715,7 +758,8 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
   for (int i = 0; i < L; ++i) {  // full scale blocks, in place on xb                        (:356-357)
     const int32_t* fr = forced_routing ? forced_routing + (int64_t)(L + i) * 4 * Mfull : nullptr;
     float* tr = trace ? trace + (int64_t)(L + i) * 4 * Mfull * D : nullptr;
-    MDM_TRY(decoder_layer(c, L + i, *tc, w.xb, w.xb16, w.xa, w.xa16, w.sc + (L + i) * scl, fr, tr));
+    int32_t* rd = g_route_dump ? g_route_dump + (int64_t)(L + i) * 4 * Mfull : nullptr;
+    MDM_TRY(decoder_layer(c, L + i, *tc, w.xb, w.xb16, w.xa, w.xa16, w.sc + (L + i) * scl, fr, tr, rd));
   }
   return linear(c, c.bf ? act_bf16(w.xb16) : act_f32(w.xb), Mfull, D, m->out, m->out_b, m->feats, out, nullptr);  // (:360)
 }
@@ -728,24 +772,25 @@ int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const Mdm
   if ((block == MDM_BLOCK_CROSS || block == MDM_BLOCK_SDCROSS || block == MDM_BLOCK_LAYER) && (!tc || tc->B != B))
     return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B, c.S = S, c.M = (int64_t)B * S, c.len = len;
+  c.m = m, c.s = (hipStream_t)stream, c.B = B, c.S = S, c.M = (int64_t)B * S, c.len = len;
+  if (!set_precision(c, m, precision)) return MDM_ERR_UNSUPPORTED;
   c.N = tc ? tc->N : 1;
   c.w = carve(*m, B, S, c.N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const MdmLayer& l = m->layers[layer];
   const int64_t scs = (int64_t)B * 2 * m->D, n = c.M * m->D;
   if (c.bf && (n & 3)) return MDM_ERR_UNSUPPORTED;
-  if (c.bf) MDM_TRY(to_bf16(h, n, c.w.h016, c.s));  // callers hand over fp32 only: build the bf16 shadow here
+  if (c.bf) MDM_TRY(to_bf16(h, n, c.w.h016, c.h16, c.s));  // callers hand over fp32 only: build the 16-bit shadow here
   switch (block) {
     case MDM_BLOCK_DUAL: return dual_block(c, l, h, c.w.h016, sc, out);
     case MDM_BLOCK_CROSS: return cross_block(c, l, tc_at(*m, *tc, layer), h, sc + 2 * scs, out);
-    case MDM_BLOCK_MOE: return moe_block(c, l, h, sc + 3 * scs, forced_routing, out, nullptr);
+    case MDM_BLOCK_MOE: return moe_block(c, l, h, sc + 3 * scs, forced_routing, out, nullptr, g_route_dump);
     case MDM_BLOCK_SDCROSS:
       return sdcross_block(c, l, tc_k(*m, *tc, layer), tc_v(*m, *tc, layer), h, c.w.h016, out, nullptr,
                            tc_fold(*m, *tc, layer));
     case MDM_BLOCK_LAYER: {
       if (hipMemcpyAsync(c.w.xa, h, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) != hipSuccess) return MDM_ERR_LAUNCH;
-      if (c.bf) MDM_TRY(to_bf16(h, n, c.w.xa16, c.s));
+      if (c.bf) MDM_TRY(to_bf16(h, n, c.w.xa16, c.h16, c.s));
       MDM_TRY(decoder_layer(c, layer, *tc, c.w.xa, c.w.xa16, c.w.xb, c.w.xb16, sc, forced_routing, nullptr));
       return hipMemcpyAsync(out, c.w.xa, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) == hipSuccess ? MDM_OK
                                                                                                          : MDM_ERR_LAUNCH;
@@ -785,13 +830,13 @@ int mdm_performer_attn_forward(const MdmModel* m, int32_t layer, int32_t which, 
   if (!h || !sc || !len || !out || !ws || B <= 0 || S <= 0 || layer < 0 || layer >= 2 * m->L || which < 0 || which > 1)
     return MDM_ERR_ARG;
   Ctx c = {};
-  c.m = m, c.s = (hipStream_t)stream, c.prec = precision, c.bf = use_bf16_acts(m, precision), c.B = B, c.S = S,
-  c.M = (int64_t)B * S, c.len = len, c.N = 1;
+  c.m = m, c.s = (hipStream_t)stream, c.B = B, c.S = S, c.M = (int64_t)B * S, c.len = len, c.N = 1;
+  if (!set_precision(c, m, precision)) return MDM_ERR_UNSUPPORTED;
   c.w = carve(*m, B, S, 1, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const MdmLayer& l = m->layers[layer];
   const MdmPerformer& p = which ? l.global : l.local;
-  MDM_TRY(ln_chain(h, c.M, m->D, p.pre_w, p.pre_b, c.w.t3, c.bf, nullptr, nullptr, nullptr, 0, c.s));
+  MDM_TRY(ln_chain(h, c.M, m->D, p.pre_w, p.pre_b, c.w.t3, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
   return performer(c, p, h, act_of(c, c.w.t3), sc, out);
 }
 
@@ -801,8 +846,9 @@ int mdm_stylization_forward(const MdmStyle* st, const float* h, const float* sc,
   MdmModel fake = {};
   fake.D = D;
   Ctx c = {};
-  c.m = &fake, c.s = (hipStream_t)stream, c.prec = precision, c.bf = (precision == 1 && D % 64 == 0), c.B = B, c.S = S,
-  c.M = (int64_t)B * S;
+  fake.F = D;
+  c.m = &fake, c.s = (hipStream_t)stream, c.B = B, c.S = S, c.M = (int64_t)B * S;
+  if (!set_precision(c, &fake, precision)) return MDM_ERR_UNSUPPORTED;
   return style_apply(c, *st, h, nullptr, nullptr, nullptr, sc, tmp, nullptr, 1.f, nullptr, out);
 }
 
@@ -831,7 +877,7 @@ int mdm_text_head_forward(const float* hidden, const float* prompts, const float
   float* pp = b.take<float>((int64_t)P * Dt);
   MdmModel fake = {};
   Ctx c = {};
-  c.m = &fake, c.s = s, c.prec = precision, c.bf = false;
+  c.m = &fake, c.s = s, c.prec = precision, c.bf = false, c.mix = false, c.h16 = MDM_H16_BF16;
   LinOpts o;
   o.act = ACT_GELU;
   if (N0 > 0) {
@@ -855,6 +901,11 @@ int mdm_motion_postprocess(const float* motion, const int32_t* length, const flo
   if (feats < 4 + 3 * (joints - 1)) return MDM_ERR_ARG;
   return motion_post(motion, length, mean, std, B, T, feats, joints, radius, weights, scratch, joints_out,
                      (hipStream_t)stream);
+}
+
+int mdm_route_dump(int32_t* buf) {
+  g_route_dump = buf;
+  return MDM_OK;
 }
 
 int mdm_probe_enable(int32_t enable) {

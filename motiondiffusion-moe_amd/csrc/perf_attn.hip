@@ -17,13 +17,12 @@ namespace {
 
 constexpr int DH = 128, MF = 128, PS = 136, NW = 8, NTH = 64 * NW;  // 8 waves: <= 2 row tiles per wave per phase  // PS: padded row stride (elements) of the 128-wide LDS images
 
-typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-
-__device__ __forceinline__ frag_t make_frag(const float* x) {
-  u32x4 u = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])};
+template <typename HT>
+__device__ __forceinline__ typename HT::frag_t make_frag(const float* x) {
+  typedef typename HT::frag_t frag_t;
+  u32x4 u = {HT::pack(x[0], x[1]), HT::pack(x[2], x[3]), HT::pack(x[4], x[5]), HT::pack(x[6], x[7])};
   return __builtin_bit_cast(frag_t, u);
 }
 
@@ -33,10 +32,12 @@ __device__ __forceinline__ float quad_sum(float v) {  // across the 4 lanes that
   return v;
 }
 
+template <typename HT>
 __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ PT,
                                                            int ldp, const float* __restrict__ hn_w,
                                                            const float* __restrict__ hn_b, const int* __restrict__ len,
                                                            int S, int H, uint16_t* __restrict__ out) {
+  typedef typename HT::frag_t frag_t;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
   uint16_t* smem = (uint16_t*)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
@@ -94,10 +95,10 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
   auto normalize = [&](const Raw& r, bool l2, float (&x)[32]) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      x[8 * ks + 0] = bf16_lo_f32(r.u[ks].x), x[8 * ks + 1] = bf16_hi_f32(r.u[ks].x);
-      x[8 * ks + 2] = bf16_lo_f32(r.u[ks].y), x[8 * ks + 3] = bf16_hi_f32(r.u[ks].y);
-      x[8 * ks + 4] = bf16_lo_f32(r.u[ks].z), x[8 * ks + 5] = bf16_hi_f32(r.u[ks].z);
-      x[8 * ks + 6] = bf16_lo_f32(r.u[ks].w), x[8 * ks + 7] = bf16_hi_f32(r.u[ks].w);
+      x[8 * ks + 0] = HT::lo(r.u[ks].x), x[8 * ks + 1] = HT::hi(r.u[ks].x);
+      x[8 * ks + 2] = HT::lo(r.u[ks].y), x[8 * ks + 3] = HT::hi(r.u[ks].y);
+      x[8 * ks + 4] = HT::lo(r.u[ks].z), x[8 * ks + 5] = HT::hi(r.u[ks].z);
+      x[8 * ks + 6] = HT::lo(r.u[ks].w), x[8 * ks + 7] = HT::hi(r.u[ks].w);
     }
     float s = 0.f;
 #pragma unroll
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
     normalize(kq[it], true, x);
     frag_t a[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) a[ks] = make_frag(x + 8 * ks);
+    for (int ks = 0; ks < 4; ++ks) a[ks] = make_frag<HT>(x + 8 * ks);
     f32x4 acc[8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         const frag_t p = *(const frag_t*)(PTl + (16 * mt + r16) * PS + 32 * ks + 8 * q);
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], p, acc[mt], 0, 0, 0);  // D[t][m]
+        acc[mt] = HT::mfma16(a[ks], p, acc[mt]);  // D[t][m]
       }
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
         const int t = t0 + 4 * q + r;
         v[r] = t < nvalid ? 0.1f * exp_fast(fminf(fmaxf(acc[mt][r], -15.f), 15.f)) : 0.f;  // key mask (:69-74)
       }
-      *(uint2*)(kT + (16 * mt + r16) * TS + t0 + 4 * q) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      *(uint2*)(kT + (16 * mt + r16) * TS + t0 + 4 * q) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
     }
   }
 #pragma unroll
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        vT[(32 * ks + 8 * q + j) * TS + t] = t < S ? (uint16_t)(pack_bf16(x[8 * ks + j], 0.f) & 0xffff) : (uint16_t)0;
+        vT[(32 * ks + 8 * q + j) * TS + t] = t < S ? (uint16_t)(HT::pack(x[8 * ks + j], 0.f) & 0xffff) : (uint16_t)0;
   }
   if (TP > SP) {  // zero the K-padding columns of both images
     for (int i = tid; i < DH * 16; i += NTH) {
@@ -205,13 +206,13 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
 #pragma unroll
       for (int j = 0; j < 8; ++j) bf[j] = *(const frag_t*)(vT + (16 * j + r16) * TS + 32 * ks + 8 * q);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) acc[j] = HT::mfma16(a, bf[j], acc[j]);
     }
     // D[m][d]: col d = 16j + r16, rows m = 16w + 4q + r  ->  KV^T[d][m..m+3]
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       *(uint2*)(KV + (16 * j + r16) * PS + 16 * wid + 4 * q) =
-          make_uint2(pack_bf16(0.1f * acc[j][0], 0.1f * acc[j][1]), pack_bf16(0.1f * acc[j][2], 0.1f * acc[j][3]));
+          make_uint2(HT::pack(0.1f * acc[j][0], 0.1f * acc[j][1]), HT::pack(0.1f * acc[j][2], 0.1f * acc[j][3]));
   }
   __syncthreads();  // v^T dead: its region takes P^T again
   load_PT();
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
     normalize(kq[it], true, x);
     frag_t qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag(x + 8 * ks);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag<HT>(x + 8 * ks);
     f32x4 accf[8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) accf[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         const frag_t p = *(const frag_t*)(PTl + (16 * mt + r16) * PS + 32 * ks + 8 * q);
-        accf[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p, qf[ks], accf[mt], 0, 0, 0);  // D[m][t]
+        accf[mt] = HT::mfma16(p, qf[ks], accf[mt]);  // D[m][t]
       }
     // lane: t = t0 + r16, m = 16*mt + 4q + r
     float den = 0.f;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
       for (int r = 0; r < 4; ++r) {
         const float f = 0.1f * exp_fast(fminf(fmaxf(accf[mt][r], -15.f), 15.f));
         accf[mt][r] = f;
-        den += f * bf16_bits_to_f32(kT[(16 * mt + 4 * q + r) * TS + t]);  // same-t dot (:81)
+        den += f * HT::one(kT[(16 * mt + 4 * q + r) * TS + t]);  // same-t dot (:81)
       }
     den = fmaxf(quad_sum(den), 1e-6f);
     f32x4 accn[8];
@@ -255,15 +256,15 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       // k-slots j=0..3 <-> m = 32s + 4q + j ; j=4..7 <-> m = 32s + 16 + 4q + (j-4)
-      const u32x4 ub = {pack_bf16(accf[2 * s][0], accf[2 * s][1]), pack_bf16(accf[2 * s][2], accf[2 * s][3]),
-                        pack_bf16(accf[2 * s + 1][0], accf[2 * s + 1][1]), pack_bf16(accf[2 * s + 1][2], accf[2 * s + 1][3])};
+      const u32x4 ub = {HT::pack(accf[2 * s][0], accf[2 * s][1]), HT::pack(accf[2 * s][2], accf[2 * s][3]),
+                        HT::pack(accf[2 * s + 1][0], accf[2 * s + 1][1]), HT::pack(accf[2 * s + 1][2], accf[2 * s + 1][3])};
       const frag_t bq = __builtin_bit_cast(frag_t, ub);
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         const uint2 lo = *(const uint2*)(KV + (16 * dt + r16) * PS + 32 * s + 4 * q);
         const uint2 hi = *(const uint2*)(KV + (16 * dt + r16) * PS + 32 * s + 16 + 4 * q);
         const u32x4 ua = {lo.x, lo.y, hi.x, hi.y};
-        accn[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, ua), bq, accn[dt], 0, 0, 0);  // D[d][t]
+        accn[dt] = HT::mfma16(__builtin_bit_cast(frag_t, ua), bq, accn[dt]);  // D[d][t]
       }
     }
     // lane: t, d = 16*dt + 4q + r.  out = LN_dh(0.1 * num / den)   (:78,85-90)
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
         const f32x4 w = *(const f32x4*)(hn_w + 16 * dt + 4 * q), bb = *(const f32x4*)(hn_b + 16 * dt + 4 * q);
         const float y0 = accn[dt][0] * rstd * w[0] + bb[0], y1 = accn[dt][1] * rstd * w[1] + bb[1];
         const float y2 = accn[dt][2] * rstd * w[2] + bb[2], y3 = accn[dt][3] * rstd * w[3] + bb[3];
-        *(uint2*)(orow + 16 * dt + 4 * q) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+        *(uint2*)(orow + 16 * dt + 4 * q) = make_uint2(HT::pack(y0, y1), HT::pack(y2, y3));
       }
     }
   }
@@ -303,20 +304,26 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
 
 bool perf_attn_supported(int dh, int S) { return dh == DH && S >= 1 && S <= 224; }
 
-int perf_attn(const void* qkv, int qkv_bf16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
+// h16: format (MDM_H16_*) of the qkv rows, of the feature matrix P^T and of the output rows
+int perf_attn(const void* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s) {
-  if (!perf_attn_supported(dh, S) || !qkv_bf16) return MDM_ERR_UNSUPPORTED;
+  if (!perf_attn_supported(dh, S) || (h16 != MDM_H16_BF16 && h16 != MDM_H16_F16)) return MDM_ERR_UNSUPPORTED;
   if (!qkv || !PT || !hn_w || !hn_b || !len || !out || (ldp & 7)) return MDM_ERR_ARG;
   const int TP = (S + 31) & ~31, TS = TP + 8;
   const int vreg = (DH * TS > MF * PS) ? DH * TS : MF * PS;
   const int smem = (MF * TS + vreg + DH * PS) * 2;
   static int attr = 0;
   if (smem > attr) {
-    if (hipFuncSetAttribute((const void*)perf_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)perf_attn_kernel<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)perf_attn_kernel<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr = smem;
   }
-  hipLaunchKernelGGL(perf_attn_kernel, dim3(B * H), dim3(NTH), smem, s, (const uint16_t*)qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
+  if (h16 == MDM_H16_F16) {
+    hipLaunchKernelGGL(perf_attn_kernel<HF>, dim3(B * H), dim3(NTH), smem, s, (const uint16_t*)qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
+  } else {
+    hipLaunchKernelGGL(perf_attn_kernel<HB>, dim3(B * H), dim3(NTH), smem, s, (const uint16_t*)qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
+  }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

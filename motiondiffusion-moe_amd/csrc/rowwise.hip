@@ -28,19 +28,19 @@ struct Row {
       }
     }
   }
-  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ p, int D, int lane) {
+  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ p, int D, int lane, int fmt = 1) {
     if constexpr (VEC) {
 #pragma unroll
       for (int c = 0; c < NE / 4; ++c) {
         const uint2 u = *(const uint2*)(p + 4 * (lane + 64 * c));
-        e[4 * c + 0] = bf16_lo_f32(u.x), e[4 * c + 1] = bf16_hi_f32(u.x);
-        e[4 * c + 2] = bf16_lo_f32(u.y), e[4 * c + 3] = bf16_hi_f32(u.y);
+        e[4 * c + 0] = h16_lo_f32(fmt, u.x), e[4 * c + 1] = h16_hi_f32(fmt, u.x);
+        e[4 * c + 2] = h16_lo_f32(fmt, u.y), e[4 * c + 3] = h16_hi_f32(fmt, u.y);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
         const int i = lane + 64 * j;
-        e[j] = i < D ? __uint_as_float(((uint32_t)p[i]) << 16) : 0.f;
+        e[j] = i < D ? h16_lo_f32(fmt, (uint32_t)p[i]) : 0.f;
       }
     }
   }
@@ -60,22 +60,22 @@ struct Row {
     }
   }
   // bf16 (round-to-nearest-even) copy of the row, for tensors whose only consumer is a bf16 MFMA GEMM
-  __device__ __forceinline__ void store_bf16(uint16_t* __restrict__ p, int D, int lane) const {
+  __device__ __forceinline__ void store_bf16(uint16_t* __restrict__ p, int D, int lane, int fmt = 1) const {
     if constexpr (VEC) {
 #pragma unroll
       for (int c = 0; c < NE / 4; ++c)
-        *(uint2*)(p + 4 * (lane + 64 * c)) = make_uint2(pack_bf16(e[4 * c + 0], e[4 * c + 1]), pack_bf16(e[4 * c + 2], e[4 * c + 3]));
+        *(uint2*)(p + 4 * (lane + 64 * c)) = make_uint2(pack_h16(fmt, e[4 * c + 0], e[4 * c + 1]), pack_h16(fmt, e[4 * c + 2], e[4 * c + 3]));
     } else {
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
         const int i = lane + 64 * j;
-        if (i < D) p[i] = (uint16_t)(pack_bf16(e[j], 0.f) & 0xffff);
+        if (i < D) p[i] = (uint16_t)(pack_h16(fmt, e[j], 0.f) & 0xffff);
       }
     }
   }
   __device__ __forceinline__ void store_as(void* __restrict__ p, int64_t row, int D, int lane, int bf16) const {
-    if (bf16) {
-      store_bf16((uint16_t*)p + row * D, D, lane);
+    if (bf16) {  // format code: 1 = bf16, 2 = fp16
+      store_bf16((uint16_t*)p + row * D, D, lane, bf16);
     } else {
       store((float*)p + row * D, D, lane);
     }
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
     const bool two = row + 1 < M;
     Row<NE, VEC> r, q;
     if (x_bf) {
-      r.load_bf16((const uint16_t*)x + row * D, D, lane);
-      q.load_bf16((const uint16_t*)x + (two ? row + 1 : row) * D, D, lane);
+      r.load_bf16((const uint16_t*)x + row * D, D, lane, x_bf);
+      q.load_bf16((const uint16_t*)x + (two ? row + 1 : row) * D, D, lane, x_bf);
     } else {
       r.load(x + row * D, D, lane);
       q.load(x + (two ? row + 1 : row) * D, D, lane);
@@ -176,10 +176,10 @@ __global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__
       Row<NE, VEC> a, b, c, d;
       if (x_bf) {
         const uint16_t* xh = (const uint16_t*)x;
-        a.load_bf16(xh + (int64_t)pos4[row * 4 + 0] * D, D, lane);
-        b.load_bf16(xh + (int64_t)pos4[row * 4 + 1] * D, D, lane);
-        c.load_bf16(xh + (int64_t)pos4[row * 4 + 2] * D, D, lane);
-        d.load_bf16(xh + (int64_t)pos4[row * 4 + 3] * D, D, lane);
+        a.load_bf16(xh + (int64_t)pos4[row * 4 + 0] * D, D, lane, x_bf);
+        b.load_bf16(xh + (int64_t)pos4[row * 4 + 1] * D, D, lane, x_bf);
+        c.load_bf16(xh + (int64_t)pos4[row * 4 + 2] * D, D, lane, x_bf);
+        d.load_bf16(xh + (int64_t)pos4[row * 4 + 3] * D, D, lane, x_bf);
       } else {
         a.load(x + (int64_t)pos4[row * 4 + 0] * D, D, lane);
         b.load(x + (int64_t)pos4[row * 4 + 1] * D, D, lane);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < NE; ++j) r.e[j] = ((a.e[j] + b.e[j]) + (c.e[j] + d.e[j])) * 0.5f;
     } else if (x_bf) {
-      r.load_bf16((const uint16_t*)x + row * D, D, lane);
+      r.load_bf16((const uint16_t*)x + row * D, D, lane, x_bf);
     } else {
       r.load(x + row * D, D, lane);
     }
@@ -253,11 +253,13 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
         logit[e] = e < E ? expf(logit[e] - mx) : 0.f;
         den += logit[e];
       }
-      int i1 = 0, i2 = -1;
+      // top-2 is TOTAL: a row of non-finite logits still yields two distinct in-range experts (its outputs are NaN, which
+      // is the wanted signal); every `>` below is false for NaN, so the initial pair survives
+      int i1 = 0, i2 = 1;
       float v1 = -1.f, v2 = -1.f;
       if (p.forced_idx) {  // test hook: routing injected, probabilities still computed here
-        i1 = p.forced_idx[((int64_t)br * M + row) * 2 + 0];
-        i2 = p.forced_idx[((int64_t)br * M + row) * 2 + 1];
+        i1 = min(max(p.forced_idx[((int64_t)br * M + row) * 2 + 0], 0), E - 1);
+        i2 = min(max(p.forced_idx[((int64_t)br * M + row) * 2 + 1], 0), E - 1);
         v1 = v2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -277,6 +279,10 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
               v2 = pe, i2 = e;
             }
           }
+        }
+        if (!(v2 >= 0.f)) {  // non-finite probabilities: keep the pair distinct and report NaN weights
+          i2 = i1 == 0 ? 1 : 0;
+          v1 = v2 = __int_as_float(0x7fc00000);
         }
       }
       if (lane == 0) {
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
                          v[c][3] * rstd * w[3] + b[3]};
         if (ok) {
           if (p.hn_bf16) {
-            *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_bf16(h[0], h[1]), pack_bf16(h[2], h[3]));
+            *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_h16(p.hn_bf16, h[0], h[1]), pack_h16(p.hn_bf16, h[2], h[3]));
           } else {
             *(f32x4*)((float*)p.hn + ((int64_t)br * M + row) * D + k) = h;
           }
@@ -375,11 +381,13 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
         }
       }
       const float den = group_sum<16>(l16 < E ? expf(mine - mx) : 0.f);
-      int i1 = 0, i2 = -1;
+      // top-2 is TOTAL (see moe_gate_kernel): NaN logits fail every `>`, the distinct in-range initial pair survives and the
+      // probabilities (hence the token's outputs) come out NaN instead of an out-of-range index
+      int i1 = 0, i2 = 1;
       float l1 = -INFINITY, l2 = -INFINITY;
       if (p.forced_idx) {
-        i1 = p.forced_idx[((int64_t)br * M + rc) * 2 + 0];
-        i2 = p.forced_idx[((int64_t)br * M + rc) * 2 + 1];
+        i1 = min(max(p.forced_idx[((int64_t)br * M + rc) * 2 + 0], 0), E - 1);
+        i2 = min(max(p.forced_idx[((int64_t)br * M + rc) * 2 + 1], 0), E - 1);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           l1 = e == i1 ? logit[e] : l1;
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
             }
           }
         }
+        if (i2 == i1) i2 = i1 == 0 ? 1 : 0;  // only reachable with non-finite logits
       }
       const float v1 = expf(l1 - mx) / den, v2 = expf(l2 - mx) / den;
       if (ok && l16 == 0) {
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(256) void moe_assign_kernel(const int* __restrict__
       br = i / (2 * M);
       const int64_t rem = i - br * 2 * M;
       tok = rem >> 1, k = (int)(rem & 1);
-      g = (int)br * E + top_idx[i];
+      g = (int)br * E + min(max(top_idx[i], 0), E - 1);
       rank = atomicAdd(&s_cnt[g], 1);
     }
     __syncthreads();
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(256) void den_ln_kernel(const float* __restrict__ n
     v = (f32x4){v[0] / den, v[1] / den, v[2] / den, v[3] / den};
     head_ln<G>(v, w, b, dh, gl);
     if (out_bf) {
-      *(uint2*)((uint16_t*)out + u * dh + 4 * gl) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      *(uint2*)((uint16_t*)out + u * dh + 4 * gl) = make_uint2(pack_h16(out_bf, v[0], v[1]), pack_h16(out_bf, v[2], v[3]));
     } else {
       *(f32x4*)((float*)out + u * dh + 4 * gl) = v;
     }
@@ -677,7 +686,7 @@ __global__ void text_assemble_kernel(const float* __restrict__ pp, const float* 
 // same with t looked up in a per-timestep table (stem cache) and an optional bf16 copy of the result
 __global__ void gated_mix_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ ts, int steps,
                                         const float* __restrict__ x, int B, int D, float* __restrict__ out,
-                                        uint16_t* __restrict__ out16) {
+                                        uint16_t* __restrict__ out16, int fmt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
   const int b = i / D, c = i - b * D;
@@ -687,7 +696,7 @@ __global__ void gated_mix_gather_kernel(const float* __restrict__ table, const i
   const float g = 1.f / (1.f + expf(-(tv + xv)));
   const float v = g * tv + (1.f - g) * xv;
   if (out) out[i] = v;
-  if (out16) out16[i] = (uint16_t)(pack_bf16(v, 0.f) & 0xffff);
+  if (out16) out16[i] = (uint16_t)(pack_h16(fmt, v, 0.f) & 0xffff);
 }
 
 __global__ void iota_i64_kernel(int64_t* dst, int64_t n, int64_t start) {
@@ -713,7 +722,8 @@ __global__ void cfg_step_kernel(const float* __restrict__ x, const float* __rest
                                 const float* __restrict__ eps_u, const float* __restrict__ noise, int64_t n,
                                 const float* __restrict__ tab, int ts, const int* __restrict__ t_ptr, int t_imm, float cfg_scale, int clip,
                                 float* __restrict__ x_out, float* __restrict__ x0_out) {
-  const int t = t_ptr ? *t_ptr : t_imm;
+  int t = t_ptr ? *t_ptr : t_imm;
+  t = min(max(t, 0), ts - 1);  // a stale device counter must not index outside the table
   const float a = tab[TAB_SQRT_RECIP * ts + t], b = tab[TAB_SQRT_RECIPM1 * ts + t];
   const float c1 = tab[TAB_COEF1 * ts + t], c2 = tab[TAB_COEF2 * ts + t];
   const float sd = t == 0 ? 0.f : expf(0.5f * tab[TAB_LOGVAR * ts + t]);
@@ -737,7 +747,8 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
                                  const float* __restrict__ noise, int64_t n, const float* __restrict__ tab, int ts,
                                  const int* __restrict__ t_ptr, int t_imm, float eta, int clip,
                                  float* __restrict__ x_out, float* __restrict__ x0_out) {
-  const int t = t_ptr ? *t_ptr : t_imm;
+  int t = t_ptr ? *t_ptr : t_imm;
+  t = min(max(t, 0), ts - 1);
   const float a = tab[TAB_SQRT_RECIP * ts + t], b = tab[TAB_SQRT_RECIPM1 * ts + t];
   const float ab = tab[TAB_ACP * ts + t], abp = tab[TAB_ACP_PREV * ts + t];
   const float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
@@ -754,10 +765,10 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
-__global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n4, uint16_t* __restrict__ dst) {
+__global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n4, uint16_t* __restrict__ dst, int fmt) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const f32x4 v = *(const f32x4*)(src + 4 * i);
-    *(uint2*)(dst + 4 * i) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    *(uint2*)(dst + 4 * i) = make_uint2(pack_h16(fmt, v[0], v[1]), pack_h16(fmt, v[2], v[3]));
   }
 }
 
@@ -910,8 +921,8 @@ int text_assemble(const float* pp, const float* ph, int B, int N0, int P, int Dt
 }
 
 int gated_mix_gather(const float* table, const int64_t* ts, int steps, const float* x, int B, int D, float* out,
-                     uint16_t* out16, hipStream_t s) {
-  hipLaunchKernelGGL(gated_mix_gather_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, table, ts, steps, x, B, D, out, out16);
+                     uint16_t* out16, int h16, hipStream_t s) {
+  hipLaunchKernelGGL(gated_mix_gather_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, table, ts, steps, x, B, D, out, out16, h16);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
@@ -934,11 +945,11 @@ int halve_lengths(const int* len, int B, int* out, hipStream_t s) {
   return MDM_OK;
 }
 
-int to_bf16(const float* src, int64_t n, uint16_t* dst, hipStream_t s) {
+int to_bf16(const float* src, int64_t n, uint16_t* dst, int h16, hipStream_t s) {
   if (n <= 0) return MDM_OK;
   if (n & 3) return MDM_ERR_ARG;
   int64_t blocks = (n / 4 + 255) / 256;
-  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, src, n / 4, dst);
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, src, n / 4, dst, h16);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

@@ -26,8 +26,6 @@ constexpr int SC_LD = 132;              // fp32 score row stride (floats)
 constexpr int RING_B = NST * ST_B, SC_B = BM * SC_LD * 4, P_B = BM * 256, RED_B = BM * 8 * 4;
 constexpr int SMEM_B = RING_B + SC_B + P_B + 2 * RED_B;
 
-typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
-
 __device__ __forceinline__ void glds16(const void* g, uint8_t* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -37,11 +35,13 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <typename HT>
 __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict__ x16, const uint16_t* __restrict__ kfold,
                                                      const float* __restrict__ cb, const uint16_t* __restrict__ vfold,
                                                      const float* __restrict__ bout, const float* __restrict__ ln_w,
                                                      const float* __restrict__ ln_b, float* __restrict__ out32,
                                                      uint16_t* __restrict__ out16, int S, int H, int N, int ntile, int rpt) {
+  typedef typename HT::frag_t frag_t;
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   uint8_t* ring = smem;
   float* sc = (float*)(smem + RING_B);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
       for (int i = 0; i < 4; ++i) {
         const int ra = 16 * i + r16;
         const frag_t xf = *(const frag_t*)(s + ra * 128 + (((ks * 4 + q) ^ (ra & 7)) << 4));
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, xf, acc[i], 0, 0, 0);  // lane: row 16i + r16, cols 16w + 4q..
+        acc[i] = HT::mfma16(kf, xf, acc[i]);  // lane: row 16i + r16, cols 16w + 4q..
       }
     }
   }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
     for (int i = 0; i < N; ++i) {
       const int c = h * N + i;
       const float e = exp_fast(p[i] - mx) * inv;
-      *(uint16_t*)(pim + row * 256 + ((((c >> 3) ^ (row & 15))) << 4) + (c & 7) * 2) = (uint16_t)(pack_bf16(e, 0.f) & 0xffff);
+      *(uint16_t*)(pim + row * 256 + ((((c >> 3) ^ (row & 15))) << 4) + (c & 7) * 2) = (uint16_t)(HT::pack(e, 0.f) & 0xffff);
     }
   }
   __syncthreads();
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
       const int rb = 16 * wid + r16;
       const frag_t vf = *(const frag_t*)(s + rb * 256 + (((ks * 4 + q) ^ (rb & 15)) << 4));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[sidx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks][i], o[sidx][i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) o[sidx][i] = HT::mfma16(vf, pf[ks][i], o[sidx][i]);
     }
   }
 
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
       *(f32x4*)(out32 + (row0 + m) * FD + j) = v;
       const float y0 = (v[0] - mean[i]) * rstd[i] * w[0] + bb[0], y1 = (v[1] - mean[i]) * rstd[i] * w[1] + bb[1];
       const float y2 = (v[2] - mean[i]) * rstd[i] * w[2] + bb[2], y3 = (v[3] - mean[i]) * rstd[i] * w[3] + bb[3];
-      *(uint2*)(out16 + (row0 + m) * FD + j) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+      *(uint2*)(out16 + (row0 + m) * FD + j) = make_uint2(HT::pack(y0, y1), HT::pack(y2, y3));
     }
   }
 }
@@ -260,18 +260,24 @@ bool sd_fold_supported(int D, int H, int N) { return D == FD && H >= 1 && H <= 8
 
 int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const uint16_t* vfold, const float* bout,
             const float* ln_w, const float* ln_b, int B, int S, int D, int H, int N, float* out32, uint16_t* out16,
-            hipStream_t s) {
+            int h16, hipStream_t s) {
   if (!sd_fold_supported(D, H, N)) return MDM_ERR_UNSUPPORTED;
   if (!x16 || !kfold || !cb || !vfold || !bout || !ln_w || !ln_b || !out32 || !out16 || B <= 0 || S <= 0) return MDM_ERR_ARG;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)sd_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)sd_fold_kernel<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B) != hipSuccess ||
+        hipFuncSetAttribute((const void*)sd_fold_kernel<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr = true;
   }
   const int ntile = (S + BM - 1) / BM, rpt = (S + ntile - 1) / ntile;
-  hipLaunchKernelGGL(sd_fold_kernel, dim3(B * ntile), dim3(NT), SMEM_B, s, x16, kfold, cb, vfold, bout, ln_w, ln_b, out32,
-                     out16, S, H, N, ntile, rpt);
+  if (h16 == MDM_H16_F16) {
+    hipLaunchKernelGGL(sd_fold_kernel<HF>, dim3(B * ntile), dim3(NT), SMEM_B, s, x16, kfold, cb, vfold, bout, ln_w, ln_b,
+                       out32, out16, S, H, N, ntile, rpt);
+  } else {
+    hipLaunchKernelGGL(sd_fold_kernel<HB>, dim3(B * ntile), dim3(NT), SMEM_B, s, x16, kfold, cb, vfold, bout, ln_w, ln_b,
+                       out32, out16, S, H, N, ntile, rpt);
+  }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

@@ -12,11 +12,12 @@ namespace {
 constexpr int DH = 128, PS = 136, NP = 96, NS = NP + 8;  // NS: row stride (elements) of the v^T image
 constexpr int XNT = 512;  // threads per (batch, head) workgroup: 8 waves share the <= 14 row tiles
 
-typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ frag_t make_frag(const float* x) {
-  u32x4 u = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])};
+template <typename HT>
+__device__ __forceinline__ typename HT::frag_t make_frag(const float* x) {
+  typedef typename HT::frag_t frag_t;
+  u32x4 u = {HT::pack(x[0], x[1]), HT::pack(x[2], x[3]), HT::pack(x[4], x[5]), HT::pack(x[6], x[7])};
   return __builtin_bit_cast(frag_t, u);
 }
 __device__ __forceinline__ float quad_sum(float v) {
@@ -30,17 +31,17 @@ __device__ __forceinline__ float quad_max(float v) {
   return v;
 }
 // row (t0 + lane&15) of a (M, D) fp32 / bf16 matrix, head h: x[32] at k = 32*ks + 8*q + j
-template <bool IN16>
+template <typename HT, bool IN16>
 __device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t row, int D, int h, int q, float (&x)[32]) {
   if constexpr (IN16) {
     const uint16_t* p = (const uint16_t*)base + row * D + h * DH + 8 * q;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const uint4 u = *(const uint4*)(p + 32 * ks);
-      x[8 * ks + 0] = bf16_lo_f32(u.x), x[8 * ks + 1] = bf16_hi_f32(u.x);
-      x[8 * ks + 2] = bf16_lo_f32(u.y), x[8 * ks + 3] = bf16_hi_f32(u.y);
-      x[8 * ks + 4] = bf16_lo_f32(u.z), x[8 * ks + 5] = bf16_hi_f32(u.z);
-      x[8 * ks + 6] = bf16_lo_f32(u.w), x[8 * ks + 7] = bf16_hi_f32(u.w);
+      x[8 * ks + 0] = HT::lo(u.x), x[8 * ks + 1] = HT::hi(u.x);
+      x[8 * ks + 2] = HT::lo(u.y), x[8 * ks + 3] = HT::hi(u.y);
+      x[8 * ks + 4] = HT::lo(u.z), x[8 * ks + 5] = HT::hi(u.z);
+      x[8 * ks + 6] = HT::lo(u.w), x[8 * ks + 7] = HT::hi(u.w);
     }
   } else {
     const float* p = (const float*)base + row * D + h * DH + 8 * q;
@@ -53,10 +54,11 @@ __device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t 
   }
 }
 
-template <int NT32, bool IN16>  // ceil(N / 32); q stored as bf16 or fp32
+template <typename HT, int NT32, bool IN16>  // ceil(N / 32); q stored as 16-bit or fp32
 __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ qm, const float* __restrict__ kc,
                                                       const float* __restrict__ vc, int S, int H, int N,
                                                       uint16_t* __restrict__ out16, float* __restrict__ out32) {
+  typedef typename HT::frag_t frag_t;
   __shared__ __attribute__((aligned(16))) uint16_t kL[NT32 * 32 * PS];  // k [n][d]
   __shared__ __attribute__((aligned(16))) uint16_t vT[DH * NS];         // v^T [d][n]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
@@ -68,19 +70,19 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
       kv = *(const f32x4*)(kc + ((int64_t)(b * N + n)) * D + h * DH + 4 * c);
       vv = *(const f32x4*)(vc + ((int64_t)(b * N + n)) * D + h * DH + 4 * c);
     }
-    *(uint2*)(kL + n * PS + 4 * c) = make_uint2(pack_bf16(kv[0], kv[1]), pack_bf16(kv[2], kv[3]));
+    *(uint2*)(kL + n * PS + 4 * c) = make_uint2(HT::pack(kv[0], kv[1]), HT::pack(kv[2], kv[3]));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vT[(4 * c + j) * NS + n] = (uint16_t)(pack_bf16(vv[j], 0.f) & 0xffff);
+    for (int j = 0; j < 4; ++j) vT[(4 * c + j) * NS + n] = (uint16_t)(HT::pack(vv[j], 0.f) & 0xffff);
   }
   __syncthreads();
   const int ntile = (S + 15) >> 4;
   for (int tile = wid; tile < ntile; tile += XNT / 64) {
     const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
     float x[32];
-    load_row<IN16>(qm, (int64_t)b * S + tc, D, h, q, x);
+    load_row<HT, IN16>(qm, (int64_t)b * S + tc, D, h, q, x);
     frag_t qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag(x + 8 * ks);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag<HT>(x + 8 * ks);
     f32x4 sc[2 * NT32];
 #pragma unroll
     for (int nt = 0; nt < 2 * NT32; ++nt) sc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
 #pragma unroll
       for (int nt = 0; nt < 2 * NT32; ++nt) {
         const frag_t kf = *(const frag_t*)(kL + (16 * nt + r16) * PS + 32 * ks + 8 * q);
-        sc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[nt], 0, 0, 0);  // D[n][t]
+        sc[nt] = HT::mfma16(kf, qf[ks], sc[nt]);  // D[n][t]
       }
     // lane: t, n = 16*nt + 4q + r.  softmax over n (no text mask in the reference, :317-320)
     float mx = -INFINITY;
@@ -115,32 +117,33 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
     for (int dt = 0; dt < 8; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NT32; ++s) {
-      const u32x4 ub = {pack_bf16(sc[2 * s][0] * inv, sc[2 * s][1] * inv), pack_bf16(sc[2 * s][2] * inv, sc[2 * s][3] * inv),
-                        pack_bf16(sc[2 * s + 1][0] * inv, sc[2 * s + 1][1] * inv),
-                        pack_bf16(sc[2 * s + 1][2] * inv, sc[2 * s + 1][3] * inv)};
+      const u32x4 ub = {HT::pack(sc[2 * s][0] * inv, sc[2 * s][1] * inv), HT::pack(sc[2 * s][2] * inv, sc[2 * s][3] * inv),
+                        HT::pack(sc[2 * s + 1][0] * inv, sc[2 * s + 1][1] * inv),
+                        HT::pack(sc[2 * s + 1][2] * inv, sc[2 * s + 1][3] * inv)};
       const frag_t pf = __builtin_bit_cast(frag_t, ub);
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         const uint2 lo = *(const uint2*)(vT + (16 * dt + r16) * NS + 32 * s + 4 * q);
         const uint2 hi = *(const uint2*)(vT + (16 * dt + r16) * NS + 32 * s + 16 + 4 * q);
         const u32x4 ua = {lo.x, lo.y, hi.x, hi.y};
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_t, ua), pf, o[dt], 0, 0, 0);  // D[d][t]
+        o[dt] = HT::mfma16(__builtin_bit_cast(frag_t, ua), pf, o[dt]);  // D[d][t]
       }
     }
     if (t < S) {
       const int64_t off = ((int64_t)b * S + t) * D + h * DH;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
-        if (out16) *(uint2*)(out16 + off + 16 * dt + 4 * q) = make_uint2(pack_bf16(o[dt][0], o[dt][1]), pack_bf16(o[dt][2], o[dt][3]));
+        if (out16) *(uint2*)(out16 + off + 16 * dt + 4 * q) = make_uint2(HT::pack(o[dt][0], o[dt][1]), HT::pack(o[dt][2], o[dt][3]));
         if (out32) *(f32x4*)(out32 + off + 16 * dt + 4 * q) = o[dt];
       }
     }
   }
 }
 
-template <bool IN16>
+template <typename HT, bool IN16>
 __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__ ql, const float* __restrict__ at, int S,
                                                         int H, float* __restrict__ out, uint16_t* __restrict__ out16) {
+  typedef typename HT::frag_t frag_t;
   __shared__ __attribute__((aligned(16))) uint16_t aL[DH * PS];  // A^T [l][d]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
@@ -148,14 +151,14 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
   for (int i = tid; i < DH * (DH / 4); i += XNT) {
     const int l = i / (DH / 4), c = i - l * (DH / 4);
     const f32x4 v = *(const f32x4*)(ab + l * DH + 4 * c);
-    *(uint2*)(aL + l * PS + 4 * c) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    *(uint2*)(aL + l * PS + 4 * c) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
   }
   __syncthreads();
   const int ntile = (S + 15) >> 4;
   for (int tile = wid; tile < ntile; tile += XNT / 64) {
     const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
     float x[32];
-    load_row<IN16>(ql, (int64_t)b * S + tc, D, h, q, x);
+    load_row<HT, IN16>(ql, (int64_t)b * S + tc, D, h, q, x);
     float mx = -INFINITY;  // softmax over head_dim (:248)
 #pragma unroll
     for (int i = 0; i < 32; ++i) mx = fmaxf(mx, x[i]);
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
     for (int i = 0; i < 32; ++i) x[i] *= inv;
     frag_t qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag(x + 8 * ks);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag<HT>(x + 8 * ks);
     f32x4 y[8];
 #pragma unroll
     for (int lt = 0; lt < 8; ++lt) y[lt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -180,13 +183,13 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
 #pragma unroll
       for (int lt = 0; lt < 8; ++lt) {
         const frag_t af = *(const frag_t*)(aL + (16 * lt + r16) * PS + 32 * ks + 8 * q);
-        y[lt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, qf[ks], y[lt], 0, 0, 0);  // D[l][t]
+        y[lt] = HT::mfma16(af, qf[ks], y[lt]);  // D[l][t]
       }
     if (t < S && out16) {
       uint16_t* orow = out16 + ((int64_t)b * S + t) * D + h * DH;
 #pragma unroll
       for (int lt = 0; lt < 8; ++lt)
-        *(uint2*)(orow + 16 * lt + 4 * q) = make_uint2(pack_bf16(y[lt][0], y[lt][1]), pack_bf16(y[lt][2], y[lt][3]));
+        *(uint2*)(orow + 16 * lt + 4 * q) = make_uint2(HT::pack(y[lt][0], y[lt][1]), HT::pack(y[lt][2], y[lt][3]));
     } else if (t < S) {
       float* orow = out + ((int64_t)b * S + t) * D + h * DH;
 #pragma unroll
@@ -199,12 +202,22 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
 
 bool xattn_supported(int dh, int N) { return dh == DH && N >= 1 && N <= NP; }
 
-int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
-            float* out32, hipStream_t s) {
+// q_fmt: 0 = fp32 q rows, 1 / 2 = bf16 / fp16 rows; h16: operand format of the MFMAs and of out16 (MDM_H16_*)
+int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
+            float* out32, int h16, hipStream_t s) {
+  const int q_bf16 = q_fmt != 0;
+  if (q_fmt && q_fmt != h16) return MDM_ERR_ARG;
   if (!xattn_supported(dh, N)) return MDM_ERR_UNSUPPORTED;
   if (!q || !kc || !vc || (!out16 && !out32)) return MDM_ERR_ARG;
   const dim3 grid(B * H), block(XNT);
-#define MDM_SD(NT, I16) hipLaunchKernelGGL((sd_attn_kernel<NT, I16>), grid, block, 0, s, q, kc, vc, S, H, N, out16, out32)
+#define MDM_SD(NT, I16)                                                                                              \
+  do {                                                                                                               \
+    if (h16 == MDM_H16_F16) {                                                                                        \
+      hipLaunchKernelGGL((sd_attn_kernel<HF, NT, I16>), grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);        \
+    } else {                                                                                                         \
+      hipLaunchKernelGGL((sd_attn_kernel<HB, NT, I16>), grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);        \
+    }                                                                                                                \
+  } while (0)
   if (N <= 32) {
     if (q_bf16) MDM_SD(1, true); else MDM_SD(1, false);
   } else if (N <= 64) {
@@ -217,14 +230,21 @@ int sd_attn(const void* q, int q_bf16, const float* kc, const float* vc, int B, 
   return MDM_OK;
 }
 
-int lin_xattn(const void* ql, int ql_bf16, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
-              hipStream_t s) {
+int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
+              int h16, hipStream_t s) {
   if (dh != DH) return MDM_ERR_UNSUPPORTED;
-  if (!ql || !at || (!out && !out16)) return MDM_ERR_ARG;
-  if (ql_bf16) {
-    hipLaunchKernelGGL(lin_xattn_kernel<true>, dim3(B * H), dim3(XNT), 0, s, ql, at, S, H, out, out16);
+  if (!ql || !at || (!out && !out16) || (ql_fmt && ql_fmt != h16)) return MDM_ERR_ARG;
+  const dim3 grid(B * H), block(XNT);
+  if (h16 == MDM_H16_F16) {
+    if (ql_fmt) {
+      hipLaunchKernelGGL((lin_xattn_kernel<HF, true>), grid, block, 0, s, ql, at, S, H, out, out16);
+    } else {
+      hipLaunchKernelGGL((lin_xattn_kernel<HF, false>), grid, block, 0, s, ql, at, S, H, out, out16);
+    }
+  } else if (ql_fmt) {
+    hipLaunchKernelGGL((lin_xattn_kernel<HB, true>), grid, block, 0, s, ql, at, S, H, out, out16);
   } else {
-    hipLaunchKernelGGL(lin_xattn_kernel<false>, dim3(B * H), dim3(XNT), 0, s, ql, at, S, H, out, out16);
+    hipLaunchKernelGGL((lin_xattn_kernel<HB, false>), grid, block, 0, s, ql, at, S, H, out, out16);
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;

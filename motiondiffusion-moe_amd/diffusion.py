@@ -253,29 +253,30 @@ class GaussianDiffusion:
     @torch.no_grad()
     def p_sample_loop_with_cfg(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                                device=None, progress=False, cfg_scale=7.5, *, step_noise=None, use_graph=True,
-                               callback: Optional[Callable] = None):
+                               callback: Optional[Callable] = None, seed: Optional[int] = None, sample_offset: int = 0):
         """Classifier-free-guided ancestral sampling.  ``step_noise``: optional list/tensor of per-step noise (the
         reference draws ``randn_like`` each step, :1094); ``callback(i, t, x)`` is called after every step."""
         self._check_supported(denoised_fn)
         r = self._runner(model, shape, model_kwargs, device, "cfg", cfg_scale, 0.0, clip_denoised, use_graph)
-        return r.run(noise, step_noise, progress, callback)
+        return r.run(noise, step_noise, progress, callback, seed, sample_offset)
 
     @torch.no_grad()
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, before_step_fn=None, *, step_noise=None,
-                      use_graph=True):
+                      use_graph=True, seed: Optional[int] = None, sample_offset: int = 0):
         """Unguided ancestral sampling with the intended noise draw (the reference's version raises at :606)."""
         self._check_supported(denoised_fn, cond_fn)
         r = self._runner(model, shape, model_kwargs, device, "ddpm", 0.0, 0.0, clip_denoised, use_graph)
         cb = (lambda i, t, x: before_step_fn(t, x)) if before_step_fn is not None else None
-        return r.run(noise, step_noise, progress, cb)
+        return r.run(noise, step_noise, progress, cb, seed, sample_offset)
 
     @torch.no_grad()
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
-                         model_kwargs=None, device=None, progress=False, eta=0.0, *, step_noise=None, use_graph=True):
+                         model_kwargs=None, device=None, progress=False, eta=0.0, *, step_noise=None, use_graph=True,
+                         seed: Optional[int] = None, sample_offset: int = 0):
         self._check_supported(denoised_fn, cond_fn)
         r = self._runner(model, shape, model_kwargs, device, "ddim", 0.0, eta, clip_denoised, use_graph)
-        return r.run(noise, step_noise, progress, None)
+        return r.run(noise, step_noise, progress, None, seed, sample_offset)
 
     # single steps (eager): same arithmetic, returns {"sample", "pred_xstart"}
     @torch.no_grad()
@@ -305,6 +306,7 @@ class _StepRunner:
     def __init__(self, diff: GaussianDiffusion, model, shape, kw, device, mode, cfg_scale, eta, clip, use_graph,
                  streams: int = 0):
         self.d, self.model, self.mode = diff, model, mode
+        self.philox = None  # (seed, global index of row 0): per-step noise from the counter-based device generator
         self.nstreams = int(streams) if streams else int(getattr(model, "sampler_streams", 1))
         self.cfg_scale, self.eta, self.clip, self.use_graph = float(cfg_scale), float(eta), bool(clip), use_graph
         if device is None:
@@ -329,15 +331,22 @@ class _StepRunner:
             up, uo = kw.get("xf_proj_uncond"), kw.get("xf_out_uncond")
             if up is None or uo is None:
                 up, uo = model.uncond_embedding(B, self.dev)
-            if uo.shape[1] != xo.shape[1]:
-                raise ValueError("cond and uncond text embeddings must have the same token count to be batched "
-                                 f"({xo.shape[1]} vs {uo.shape[1]}): pad the shorter one the way the tokenizer pads")
-            self.xp = torch.cat([xp, up.to(self.dev, torch.float32)], 0).contiguous()
-            self.xo = torch.cat([xo, uo.to(self.dev, torch.float32)], 0).contiguous()
+            up, uo = up.to(self.dev, torch.float32), uo.to(self.dev, torch.float32)
             self.len2 = torch.cat([length, length], 0)
             self.R = 2 * B
+            # A real tokenizer gives the empty caption fewer tokens than the captions (N = 8 + 2 vs 8 + longest caption,
+            # text_encoder.py:25-43) and the reference's cross-attention has no text mask, so the shorter side must NOT
+            # be padded: then the two halves run as two B-row forwards with their own text caches (split_halves).
+            self.split_halves = uo.shape[1] != xo.shape[1]
+            if self.split_halves:
+                self.xp, self.xo = None, None
+                self.halves = [(xp.contiguous(), xo.contiguous()), (up.contiguous(), uo.contiguous())]
+            else:
+                self.xp = torch.cat([xp, up], 0).contiguous()
+                self.xo = torch.cat([xo, uo], 0).contiguous()
         else:
             self.xp, self.xo, self.len2, self.R = xp.contiguous(), xo.contiguous(), length, B
+            self.split_halves = False
         self.xx = torch.empty((self.R, T, Fe), dtype=torch.float32, device=self.dev)  # model input rows
         self.eps = torch.empty_like(self.xx)
         self.noise = torch.empty((B, T, Fe), dtype=torch.float32, device=self.dev)
@@ -348,12 +357,25 @@ class _StepRunner:
         self.graph = None
         # time-embedding chain tabulated per timestep + text half of the gated fusion: once per loop, not per step
         frozen = getattr(model, "ephemeral_mode", "frozen") == "frozen"
-        self.stem = model.stem_cache(diff.num_timesteps, self.xp) if hasattr(model, "stem_cache") and frozen else None
+        can_cache = hasattr(model, "stem_cache") and frozen
+        self.stem = model.stem_cache(diff.num_timesteps, self.xp) if can_cache and not self.split_halves else None
         # Samples never interact, so the R rows of a step can be cut into independent chunks whose forwards run
         # CONCURRENTLY on separate HIP streams (forked/joined inside the captured graph): most launches of a forward are
         # latency-bound, and two chains in flight overlap each other's prologues, DMA round trips and tails.
         self.chunks = None
-        if self.nstreams > 1 and frozen and hasattr(model, "new_workspace") and self.R % self.nstreams == 0:
+        self.side = []
+        if self.split_halves:
+            if not hasattr(model, "prepare_text"):
+                raise ValueError("cond and uncond text embeddings have different token counts; this model cannot run "
+                                 "them as separate forwards")
+            self.chunks = []
+            for c, (xp_c, xo_c) in enumerate(self.halves):  # same stream, one after the other
+                sl = slice(c * B, (c + 1) * B)
+                self.chunks.append(dict(
+                    sl=sl, xp=xp_c, xo=xo_c, len=self.len2[sl].contiguous(), tc=model.prepare_text(xo_c, private=True),
+                    stem=model.stem_cache(diff.num_timesteps, xp_c) if can_cache else None,
+                    ws=model.new_workspace(B, T, xo_c.shape[1]), stream=0))
+        elif self.nstreams > 1 and frozen and hasattr(model, "new_workspace") and self.R % self.nstreams == 0:
             n = self.R // self.nstreams
             self.side = [torch.cuda.Stream(device=self.dev) for _ in range(self.nstreams - 1)]
             self.chunks = []
@@ -364,12 +386,21 @@ class _StepRunner:
                 self.chunks.append(dict(
                     sl=sl, xp=xp_c, xo=xo_c, len=self.len2[sl].contiguous(),
                     tc=model.prepare_text(xo_c, private=True), stem=model.stem_cache(diff.num_timesteps, xp_c),
-                    ws=model.new_workspace(n, T, xo_c.shape[1])))
+                    ws=model.new_workspace(n, T, xo_c.shape[1]), stream=c))
 
     # one step on the current stream: reads self.xx[:B] (x_t), writes x_{t-1} back into it
     def _step(self, use_noise: bool):
+        with torch.cuda.device(self.dev):  # kernels go to the current stream of the sampler's device
+            self._step_on_device(use_noise)
+
+    def _step_on_device(self, use_noise: bool):
         lib, s = L.lib(), C.c_void_p(L.stream_ptr())
         B, n = self.B, self.n
+        if use_noise and self.philox is not None:  # step noise = f(seed, global sample, t, element); t read on the device
+            seed, first = self.philox
+            L.check(lib.mdm_noise_normal(C.c_void_p(self.noise.data_ptr()), C.c_int64(self.T * self.Fe), C.c_int32(B),
+                                         C.c_int64(first), C.c_uint64(seed), C.c_void_p(self.t_dev.data_ptr()), C.c_int32(0), s),
+                    "mdm_noise_normal")
         x = self.xx[:B]
         if self.R == 2 * B:
             self.xx[B:].copy_(x)
@@ -377,8 +408,8 @@ class _StepRunner:
         if self.chunks is not None:
             main = torch.cuda.current_stream()
             for i, ch in enumerate(self.chunks):
-                st = main if i == 0 else self.side[i - 1]
-                if i > 0:
+                st = main if ch["stream"] == 0 else self.side[ch["stream"] - 1]
+                if st is not main:
                     st.wait_stream(main)  # fork: x_t rows and the timestep vector are ready
                 with torch.cuda.stream(st):
                     self.model(self.xx[ch["sl"]], self.ts[ch["sl"]], ch["len"], xf_proj=ch["xp"], xf_out=ch["xo"],
@@ -420,8 +451,22 @@ class _StepRunner:
             self.model.moe_buffers()[k].copy_(v)
         torch.cuda.current_stream().synchronize()
 
-    def run(self, noise, step_noise, progress, callback):
+    def draw_xT(self, seed: int, first: int = 0):
+        """x_T for rows [first, first + B) of a global batch: the counter-based generator's MDM_NOISE_STREAM_XT stream."""
+        out = torch.empty((self.B, self.T, self.Fe), dtype=torch.float32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            L.check(L.lib().mdm_noise_normal(C.c_void_p(out.data_ptr()), C.c_int64(self.T * self.Fe), C.c_int32(self.B),
+                                             C.c_int64(first), C.c_uint64(seed), C.c_void_p(0), C.c_int32(L.NOISE_STREAM_XT),
+                                             C.c_void_p(L.stream_ptr())), "mdm_noise_normal")
+        return out
+
+    def run(self, noise, step_noise, progress, callback, seed: Optional[int] = None, sample_offset: int = 0):
+        """``seed``: draw x_T (when ``noise`` is None) and every step's noise (when ``step_noise`` is None) from the
+        counter-based device generator keyed on (seed, sample_offset + row, timestep, element): the same global sample gets
+        the same noise whatever the batch split.  Without a seed the torch generator is used, like the reference."""
         d, B = self.d, self.B
+        if seed is not None and step_noise is None:
+            self.philox = (int(seed) & 0xFFFFFFFFFFFFFFFF, int(sample_offset))
         self._prepare()
         if self.use_graph:
             g = torch.cuda.CUDAGraph()
@@ -432,7 +477,7 @@ class _StepRunner:
                 self.model.moe_buffers()[k].copy_(v)
             self.graph = g
         if noise is None:
-            noise = torch.randn((B, self.T, self.Fe), device=self.dev)
+            noise = self.draw_xT(seed, sample_offset) if seed is not None else torch.randn((B, self.T, self.Fe), device=self.dev)
         self.xx[:B].copy_(noise.to(self.dev, torch.float32))
         self.t_dev.fill_(d.num_timesteps - 1)
         it = range(d.num_timesteps)
@@ -440,7 +485,7 @@ class _StepRunner:
             from tqdm.auto import tqdm
             it = tqdm(it, desc="Sampling")
         for i in it:
-            if self._needs_noise():
+            if self._needs_noise() and self.philox is None:
                 if step_noise is not None:
                     self.noise.copy_(step_noise[i].to(self.dev, torch.float32))
                 else:
@@ -456,6 +501,8 @@ class _StepRunner:
     def single(self, x, t, noise):
         t = torch.as_tensor(t)
         t0 = int(t.flatten()[0])
+        if not 0 <= t0 < self.d.num_timesteps:
+            raise ValueError(f"timestep {t0} outside the {self.d.num_timesteps}-step schedule")
         if t.numel() > 1 and not bool((t == t0).all()):
             raise NotImplementedError("per-sample timesteps within one sampler step are not supported; "
                                       "call the model directly for that")

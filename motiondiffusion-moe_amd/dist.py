@@ -3,8 +3,9 @@
 Samples never interact inside the denoiser or the sampler, so the global batch is cut into contiguous per-rank
 shards (each sample's cond+uncond pair stays on its rank), weights are replicated, there is no per-step
 collective, and the only exchange is ONE all_gather of the final (B/world, T, feats) motion tensor
-(RCCL over xGMI on GPUs; gloo in the CPU tests).  The global x_T and per-step noise are drawn for the
-*global* batch from one seeded generator and sliced, so results do not depend on the world size.
+(RCCL over xGMI on GPUs; gloo in the CPU tests).  x_T and every step's noise come from a counter-based generator keyed
+on (seed, GLOBAL sample index, timestep, element) -- csrc/noise.hip on the device, oracle/philox_ref.py restates it -- so
+results do not depend on the world size and no rank ever materialises the global batch's noise.
 """
 from __future__ import annotations
 
@@ -34,7 +35,9 @@ def shard_kwargs(kw: Dict, lo: int, hi: int) -> Dict:
 
 
 def global_noise(shape, seed: int, steps: int = 0):
-    """x_T (and optionally per-step noise) for the GLOBAL batch, from a CPU generator (world-size invariant)."""
+    """x_T (and optionally per-step noise) for the GLOBAL batch from a CPU generator.  Host-materialised: O(steps * batch)
+    memory, kept for small offline comparisons only; the samplers use the counter-based device generator
+    (``p_sample_loop_with_cfg(..., seed=, sample_offset=)``) instead."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     x_T = torch.randn(shape, generator=g)
     step = [torch.randn(shape, generator=g) for _ in range(steps)]
@@ -57,16 +60,17 @@ def all_gather_ragged(local: torch.Tensor, B: int, group=None) -> torch.Tensor:
     return torch.cat(parts, 0)
 
 
-def sample_sharded(sample_fn, shape, model_kwargs: Dict, seed: int, steps_with_noise: int = 0, group=None):
-    """Run ``sample_fn(local_shape, local_kwargs, x_T_local, step_noise_local) -> (b, T, F)`` on this rank's shard
-    of the global batch and all_gather the result.  Works with any backend (nccl == RCCL on ROCm, gloo on CPU)."""
+def sample_sharded(sample_fn, shape, model_kwargs: Dict, seed: int, group=None):
+    """Run ``sample_fn(local_shape, local_kwargs, seed, first_global_row) -> (b, T, F)`` on this rank's shard of the global
+    batch and all_gather the result.  ``sample_fn`` draws its noise from the counter-based generator with
+    ``sample_offset=first_global_row`` (e.g. ``diffusion.p_sample_loop_with_cfg(..., seed=seed, sample_offset=first)``), so
+    the gathered tensor is the same for every world size.  Any backend (nccl == RCCL on ROCm, gloo on CPU)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = shape[0]
     lo, hi = shard_range(B, rank, world)
-    x_T, step = global_noise(tuple(shape), seed, steps_with_noise)
     local_kw = shard_kwargs(model_kwargs, lo, hi)
-    local = sample_fn((hi - lo,) + tuple(shape[1:]), local_kw, x_T[lo:hi], [s[lo:hi] for s in step] if step else None)
+    local = sample_fn((hi - lo,) + tuple(shape[1:]), local_kw, seed, lo)
     return all_gather_ragged(local, B, group)
 
 

@@ -11,22 +11,34 @@ from . import _lib as L
 
 
 class PackedWeight:
-    """bf16 planes of an fp32 [N, K] weight, K zero-padded to a multiple of 32.
-    `lo` carries rn(w - hi) for the bf16x3 (fp32-grade) mode."""
+    """16-bit planes of an fp32 [N, K] weight, K zero-padded to a multiple of 32.
+    fmt "bf16x2": bf16 hi + lo planes (`lo` = rn(w - hi), the bf16x3 fp32-grade mode; `hi` alone serves a single bf16 pass);
+    "bf16": hi plane only; "f16": one IEEE fp16 plane in `hi` (single fp16 pass, include/mdm_hip.h MDM_H16_F16)."""
 
-    def __init__(self, w: torch.Tensor, with_lo: bool = True):
+    def __init__(self, w: torch.Tensor, with_lo: bool = True, fmt: Optional[str] = None):
         L.require_cuda(w)
+        fmt = fmt or ("bf16x2" if with_lo else "bf16")
+        if fmt not in ("bf16x2", "bf16", "f16"):
+            raise ValueError(f"unknown packed weight format {fmt!r}")
+        self.fmt = fmt
+        with_lo = fmt == "bf16x2"
         w = w.detach().to(torch.float32)
         lead = w.shape[:-2]
         n, k = w.shape[-2], w.shape[-1]
         w2 = w.reshape(-1, k).contiguous()
         kp = (k + 31) // 32 * 32
         self.N, self.K, self.Kp = n, k, kp
-        self.hi = torch.empty((w2.shape[0], kp), dtype=torch.bfloat16, device=w.device)
+        self.hi = torch.empty((w2.shape[0], kp), dtype=torch.float16 if fmt == "f16" else torch.bfloat16, device=w.device)
         self.lo = torch.empty_like(self.hi) if with_lo else None
-        L.check(L.lib().mdm_pack_bf16(C.c_void_p(w2.data_ptr()), C.c_int64(k), C.c_int64(w2.shape[0]), C.c_int64(k),
-                                      C.c_void_p(self.hi.data_ptr()), C.c_void_p(L.ptr(self.lo)), C.c_int64(kp),
-                                      C.c_void_p(L.stream_ptr())), "mdm_pack_bf16")
+        with torch.cuda.device(w.device):
+            if fmt == "f16":
+                L.check(L.lib().mdm_pack_f16(C.c_void_p(w2.data_ptr()), C.c_int64(k), C.c_int64(w2.shape[0]), C.c_int64(k),
+                                             C.c_void_p(self.hi.data_ptr()), C.c_int64(kp), C.c_void_p(L.stream_ptr())),
+                        "mdm_pack_f16")
+            else:
+                L.check(L.lib().mdm_pack_bf16(C.c_void_p(w2.data_ptr()), C.c_int64(k), C.c_int64(w2.shape[0]), C.c_int64(k),
+                                              C.c_void_p(self.hi.data_ptr()), C.c_void_p(L.ptr(self.lo)), C.c_int64(kp),
+                                              C.c_void_p(L.stream_ptr())), "mdm_pack_bf16")
         self.lead = tuple(lead)
 
     def operand(self, row_offset: int = 0) -> L.Operand:
@@ -73,8 +85,10 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty((M, w.N), dtype=torch.float32, device=x.device)
     d = gemm_desc(precision)
-    if x2.dtype == torch.bfloat16:
+    if x2.dtype in (torch.bfloat16, torch.float16):  # 16-bit rows: single-pass kernel in that format (w packed alike)
+        assert (x2.dtype == torch.float16) == (w.fmt == "f16"), "activation and weight 16-bit formats must match"
         d.A.p, d.A.ld, d.A.kind = x2.data_ptr(), x2.stride(0), L.OP_BF16_ROW
+        d.precision, d.h16 = 1, (L.H16_F16 if x2.dtype == torch.float16 else L.H16_BF16)
     else:
         d.A = f32_operand(x2, x2.stride(0))
     d.W = w.operand()
@@ -83,6 +97,7 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
     if out16 is not None:
         assert out16.stride(0) == out.stride(0)
         d.C16 = out16.data_ptr()
+        d.h16 = L.H16_F16 if out16.dtype == torch.float16 else L.H16_BF16
     d.bias = L.ptr(bias)
     d.act, d.alpha, d.out_scale = act, alpha, out_scale
     d.colscale, d.rowscale = L.ptr(colscale), L.ptr(rowscale)
@@ -103,7 +118,8 @@ def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w
     """y = (GELU(x w1^T + b1) w2^T + b2) * rowscale + r1_scale * r1 + r2 with the hidden layer kept on chip (mlp.hip).
     ``goff`` (int32 [G+1], device) selects grouped mode: w1 / w2 / b1 / b2 then carry a leading group axis."""
     L.require_cuda(x16)
-    assert x16.dtype == torch.bfloat16 and x16.stride(-1) == 1
+    assert x16.dtype in (torch.bfloat16, torch.float16) and x16.stride(-1) == 1
+    assert (x16.dtype == torch.float16) == (w1.fmt == "f16") == (w2.fmt == "f16"), "16-bit formats of x, w1, w2 must match"
     x2 = x16.reshape(-1, x16.shape[-1])
     M = x2.shape[0] if rows is None else rows
     F, Dout = w1.N, w2.N
@@ -111,6 +127,7 @@ def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w
     if out is None:
         out = torch.empty((M, Dout), dtype=torch.float32, device=x16.device)
     d = L.MlpDesc()
+    d.h16 = L.H16_F16 if x16.dtype == torch.float16 else L.H16_BF16
     d.X, d.ldx, d.gather = x2.data_ptr(), x2.stride(0), L.ptr(gather)
     d.M, d.Din, d.F, d.Dout = M, w1.K, F, Dout
     if goff is not None:

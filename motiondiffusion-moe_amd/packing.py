@@ -17,6 +17,32 @@ from .synth import ephemeral_names, projection_names
 
 STYLE_SLOTS = ("local_style", "global_style", "cross_style", "ffn_style")
 
+# Weights that are always packed as bf16 hi + lo planes: they are multiplied with fp32 activations by the register-staged
+# kernel (csrc/gemm.hip) in every mode -- the per-loop stem / text caches are always built in the bf16x3 arithmetic, and
+# joint_embed reads the fp32 motion tensor itself.
+_ALWAYS_X3 = ("tmlp0", "tmlp2", "te0", "te2", "tproj", "gf_time", "gf_text", "text_proj", "joint")
+_ALWAYS_X3_LAYER = ("ca_k", "ca_v", "sd_k", "sd_v")
+_MLP_LAYER = ("w1", "w2", "sd_f1", "sd_f2")  # the MFMA-bound GEMMs: expert MLPs and the 4x FFN
+
+
+def format_class(precision: int) -> str:
+    """Packed models are shared between precisions that read the same planes."""
+    return {L.PREC_BF16: "bf16", L.PREC_X3: "bf16", L.PREC_F16: "f16", L.PREC_MIXED: "mixed"}[precision]
+
+
+def weight_format(name: str, precision: int, head_dim: int) -> str:
+    """Plane format of kernel_layout()'s matrix `name` for a run at `precision` (include/mdm_hip.h: MDM_PREC_*)."""
+    leaf = name.split(".", 1)[1] if name.startswith("L") and "." in name else name
+    if name in _ALWAYS_X3 or leaf in _ALWAYS_X3_LAYER:
+        return "bf16x2"
+    if leaf.endswith("feat") and head_dim != 128:  # no fused Performer core: the feature GEMM reads fp32 rows
+        return "bf16x2"
+    if precision == L.PREC_F16:
+        return "f16"
+    if precision == L.PREC_MIXED and leaf in _MLP_LAYER:
+        return "f16"
+    return "bf16x2"
+
 
 def layer_tags(num_layers: int) -> List[Tuple[str, str]]:
     """(state_dict prefix, captured-randomness tag) for the 2L decoder layers: low blocks then high blocks."""
@@ -118,10 +144,12 @@ class PackedModel:
     """Device-resident packed weights + the ctypes ``MdmModel`` that points at them."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: dict, eph, proj, device, with_lo: bool = True,
-                 counters: Dict[str, torch.Tensor] = None):
+                 counters: Dict[str, torch.Tensor] = None, precision: int = L.PREC_X3):
         from .ops import PackedWeight  # HIP pack kernel
 
         self.cfg = dict(cfg)
+        self.format_class = format_class(precision)
+        head_dim = cfg["latent_dim"] // cfg["num_heads"]
         dev = torch.device(device)
         if dev.type != "cuda":
             raise L.MdmError("PackedModel needs a GPU device: the denoising path has no CPU fallback")
@@ -133,7 +161,8 @@ class PackedModel:
             for k, t in lay.items():
                 t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if k.startswith("W:"):
-                    self.W[k[2:]] = PackedWeight(t, with_lo=with_lo)
+                    fmt = weight_format(k[2:], precision, head_dim)
+                    self.W[k[2:]] = PackedWeight(t, fmt=fmt if (with_lo or fmt != "bf16x2") else "bf16")
                 else:
                     self.V[k[2:]] = t
             D, L_ = cfg["latent_dim"], cfg["num_layers"]

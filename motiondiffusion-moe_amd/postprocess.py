@@ -46,10 +46,11 @@ def motion_to_joints(motion: torch.Tensor, mean, std, lengths: Optional[torch.Te
     ln = None if lengths is None else torch.as_tensor(lengths).to(dev, torch.int32).contiguous()
     scratch = torch.empty(B, T, joints_num, 3, device=dev)
     out = torch.empty_like(scratch)
-    L.check(L.lib().mdm_motion_postprocess(
-        C.c_void_p(x.data_ptr()), C.c_void_p(L.ptr(ln)), C.c_void_p(mean_t.data_ptr()), C.c_void_p(std_t.data_ptr()),
-        C.c_int32(B), C.c_int32(T), C.c_int32(Fe), C.c_int32(joints_num), C.c_int32(radius), C.c_void_p(w_t.data_ptr()),
-        C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr())), "mdm_motion_postprocess")
+    with torch.cuda.device(dev):
+        L.check(L.lib().mdm_motion_postprocess(
+            C.c_void_p(x.data_ptr()), C.c_void_p(L.ptr(ln)), C.c_void_p(mean_t.data_ptr()), C.c_void_p(std_t.data_ptr()),
+            C.c_int32(B), C.c_int32(T), C.c_int32(Fe), C.c_int32(joints_num), C.c_int32(radius), C.c_void_p(w_t.data_ptr()),
+            C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr())), "mdm_motion_postprocess")
     return out
 
 

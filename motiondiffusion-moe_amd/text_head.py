@@ -82,12 +82,13 @@ class EnhancedTextEncoder(nn.Module):
         packed = L.Packed(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.Kp)
         prompts = self.prompt_tokens.detach().to(torch.float32).reshape(P, Hs).contiguous()
         ln, lin = self.proj[0], self.proj[1]
-        L.check(lib.mdm_text_head_forward(
-            C.c_void_p(h.data_ptr()), C.c_void_p(prompts.data_ptr()), C.c_void_p(ln.weight.data_ptr()),
-            C.c_void_p(ln.bias.data_ptr()), C.byref(packed), C.c_void_p(lin.bias.data_ptr()), C.c_int32(B), C.c_int32(N0),
-            C.c_int32(P), C.c_int32(Hs), C.c_int32(Dt), C.c_void_p(xf_out.data_ptr()), C.c_void_p(xf_proj.data_ptr()),
-            C.c_void_p(ws.data_ptr()), C.c_int64(nbytes), C.c_int32(self.precision), C.c_void_p(L.stream_ptr())),
-            "mdm_text_head_forward")
+        with torch.cuda.device(h.device):
+            L.check(lib.mdm_text_head_forward(
+                C.c_void_p(h.data_ptr()), C.c_void_p(prompts.data_ptr()), C.c_void_p(ln.weight.data_ptr()),
+                C.c_void_p(ln.bias.data_ptr()), C.byref(packed), C.c_void_p(lin.bias.data_ptr()), C.c_int32(B), C.c_int32(N0),
+                C.c_int32(P), C.c_int32(Hs), C.c_int32(Dt), C.c_void_p(xf_out.data_ptr()), C.c_void_p(xf_proj.data_ptr()),
+                C.c_void_p(ws.data_ptr()), C.c_int64(nbytes), C.c_int32(self.precision), C.c_void_p(L.stream_ptr())),
+                "mdm_text_head_forward")
         return xf_proj, xf_out
 
     @torch.no_grad()

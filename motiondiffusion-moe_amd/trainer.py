@@ -38,7 +38,8 @@ class DDPMTrainer(object):
         self._model().eval()
 
     @torch.no_grad()
-    def generate_batch(self, caption, m_lens, dim_pose, *, noise=None, step_noise=None, progress=True):
+    def generate_batch(self, caption, m_lens, dim_pose, *, noise=None, step_noise=None, progress=True, seed=None,
+                       sample_offset=0):
         m = self._model()
         xf_proj, xf_out = m.encode_text(caption, self.device)
         m_lens = torch.as_tensor(m_lens)
@@ -47,17 +48,22 @@ class DDPMTrainer(object):
         return self.diffusion.p_sample_loop_with_cfg(
             m, (B, T, dim_pose), clip_denoised=False, progress=progress, noise=noise, step_noise=step_noise,
             model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out, "length": m_lens, "text": caption},
-            cfg_scale=self.cfg_scale)
+            cfg_scale=self.cfg_scale, seed=seed, sample_offset=sample_offset)
 
     @torch.no_grad()
-    def generate(self, caption, m_lens, dim_pose, batch_size=8, *, progress=False):
+    def generate(self, caption, m_lens, dim_pose, batch_size=8, *, progress=False, seed=None, noises=None):
+        """``seed``: sample i's noise is then a function of (seed, i) only (counter-based device generator), so the result
+        does not depend on ``batch_size``; without it the torch generator is used, as in the reference.
+        ``noises``: optional list with one ``(x_T, [step noise, ...])`` pair per batch, replacing the draws (parity tests)."""
         N = len(caption)
         self.eval_mode()
         all_output = []
         cur = 0
         while cur < N:
             end = min(cur + batch_size, N)
-            out = self.generate_batch(caption[cur:end], m_lens[cur:end], dim_pose, progress=progress)
+            x_T, step_noise = noises[cur // batch_size] if noises is not None else (None, None)
+            out = self.generate_batch(caption[cur:end], m_lens[cur:end], dim_pose, progress=progress, seed=seed,
+                                      sample_offset=cur, noise=x_T, step_noise=step_noise)
             all_output.extend(out[i] for i in range(out.shape[0]))
             cur += batch_size
         return all_output
@@ -76,14 +82,13 @@ class DDPMTrainer(object):
         plan = D.plan_buckets(lens, batch_size, m.num_frames, unit_length)
 
         def run_bucket(k, idx, T):
-            if seed is not None:
-                torch.manual_seed(int(seed) + k)
             cap = [caption[i] for i in idx.tolist()]
             ln = lens[idx].clamp(max=T).to(self.device)
             xf_proj, xf_out = m.encode_text(cap, self.device)
             return self.diffusion.p_sample_loop_with_cfg(
                 m, (len(cap), T, dim_pose), clip_denoised=False, progress=progress,
-                model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out, "length": ln, "text": cap}, cfg_scale=self.cfg_scale)
+                model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out, "length": ln, "text": cap}, cfg_scale=self.cfg_scale,
+                seed=None if seed is None else (int(seed) * 1000003 + k))  # bucket k: its own stream of the generator
 
         return D.run_plan(plan, run_bucket, len(caption), m.num_frames, dim_pose, self.device, group)
 

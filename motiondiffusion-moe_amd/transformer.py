@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .layout import BUFFER_LEAVES, resolve_dims, state_dict_layout
-from .packing import PackedModel
+from .packing import PackedModel, format_class
 from .synth import ephemeral_names, projection_names
 
 
@@ -48,6 +48,8 @@ class MotionTransformer(nn.Module):
         self.num_layers, self.num_heads, self.dropout = num_layers, num_heads, dropout
         self.moe_num_experts, self.chunk_size = moe_num_experts, chunk_size
         self.time_embed_dim = 4 * D
+        if precision not in L.PRECISIONS:
+            raise ValueError(f"precision must be one of {L.PRECISIONS} (include/mdm_hip.h: MDM_PREC_*)")
         self.precision = precision
         if ephemeral_mode not in ("frozen", "resample"):
             raise ValueError("ephemeral_mode must be 'frozen' or 'resample'")
@@ -72,7 +74,7 @@ class MotionTransformer(nn.Module):
         self.text_encoder_fn = text_encoder
         self._eph: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None
         self._proj: Optional[Dict[str, torch.Tensor]] = None
-        self._packed: Optional[PackedModel] = None
+        self._packed: Dict[str, PackedModel] = {}  # per weight-format class (packing.format_class)
         self._text_cache = None
         self._ws: Optional[torch.Tensor] = None
         self._uncond: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -123,9 +125,11 @@ class MotionTransformer(nn.Module):
 
     def invalidate(self):
         """Forget packed weights / caches (call after mutating parameters in place)."""
-        self._packed = None
+        self._packed = {}
         self._text_cache = None
         self._time_table = None
+        if not getattr(self, "_uncond_explicit", False):
+            self._uncond = None  # encoded by the (possibly reloaded) text encoder: must be re-encoded
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -228,6 +232,7 @@ class MotionTransformer(nn.Module):
     def set_uncond_embedding(self, xf_proj: torch.Tensor, xf_out: torch.Tensor):
         """Cached embedding of the empty caption used by classifier-free guidance (one row, broadcast over B)."""
         self._uncond = (xf_proj, xf_out)
+        self._uncond_explicit = True
 
     def uncond_embedding(self, B: int, device):
         if self._uncond is None:
@@ -250,12 +255,13 @@ class MotionTransformer(nn.Module):
             self.draw_ephemerals()
         if self._proj is None:
             self.draw_projections()
-        if self._packed is None:
+        cls = format_class(self.precision)
+        if cls not in self._packed:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            self._packed = PackedModel(sd, self.kernel_cfg(), self._eph, self._proj, self.device,
-                                       with_lo=True, counters=self.moe_buffers())
+            self._packed[cls] = PackedModel(sd, self.kernel_cfg(), self._eph, self._proj, self.device,
+                                            with_lo=True, counters=self.moe_buffers(), precision=self.precision)
             self._text_cache = None
-        return self._packed
+        return self._packed[cls]
 
     def workspace_bytes(self, B: int, T: int, N: int) -> int:
         pm = self.pack()
@@ -278,7 +284,7 @@ class MotionTransformer(nn.Module):
         """Build (or fetch) the text-side cache for this xf_out [B,N,Dt].  ``private=True`` returns a cache object
         owned by the caller (pass it back as ``forward(..., text_cache=)``) instead of the module's single slot."""
         pm = self.pack()
-        xf_out = xf_out.detach().to(torch.float32).contiguous()
+        xf_out = xf_out.detach().to(device=self.device, dtype=torch.float32).contiguous()
         B, N, Dt = xf_out.shape
         if Dt != self.text_latent_dim:
             raise ValueError(f"xf_out last dim {Dt} != text_latent_dim {self.text_latent_dim}")
@@ -294,16 +300,18 @@ class MotionTransformer(nn.Module):
         tc = L.TextCache()
         tc.lin_at, tc.sd_k, tc.sd_v, tc.B, tc.N = at.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, N
         fold = ()
-        if self.precision == 1 and D == 512 and H * N <= 128:
-            # throughput mode: query / output projections of the text cross-attention folded into the text side
-            fold = (torch.zeros((L2, B, 128, D), dtype=torch.bfloat16, device=dev),
+        if self.precision in (L.PREC_BF16, L.PREC_F16) and D == 512 and H * N <= 128:
+            # throughput modes: query / output projections of the text cross-attention folded into the text side
+            h16 = torch.float16 if self.precision == L.PREC_F16 else torch.bfloat16
+            fold = (torch.zeros((L2, B, 128, D), dtype=h16, device=dev),
                     torch.zeros((L2, B, 128), dtype=torch.float32, device=dev),
-                    torch.zeros((L2, B, D, 128), dtype=torch.bfloat16, device=dev))
+                    torch.zeros((L2, B, D, 128), dtype=h16, device=dev))
             tc.sd_kfold, tc.sd_cb, tc.sd_vfold = (t.data_ptr() for t in fold)
         ws = self._workspace(B, 2, N)
-        L.check(L.lib().mdm_text_cache_build(C.byref(pm.model), C.c_void_p(xf_out.data_ptr()), C.byref(tc),
-                                             C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
-                                             C.c_void_p(L.stream_ptr())), "mdm_text_cache_build")
+        with torch.cuda.device(dev):  # launches go to the current stream OF THE MODEL'S DEVICE, whatever device is current
+            L.check(L.lib().mdm_text_cache_build(C.byref(pm.model), C.c_void_p(xf_out.data_ptr()), C.byref(tc),
+                                                 C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
+                                                 C.c_void_p(L.stream_ptr())), "mdm_text_cache_build")
         cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out) + fold, "B": B, "N": N, "pm": pm}
         if not private:
             self._text_cache = cache
@@ -324,10 +332,11 @@ class MotionTransformer(nn.Module):
         xp = xf_proj.detach().to(device=dev, dtype=torch.float32).contiguous()
         gx = torch.empty((xp.shape[0], D), dtype=torch.float32, device=dev)
         ws = self._workspace(128, 2, 1)
-        L.check(L.lib().mdm_stem_cache_build(C.byref(pm.model), C.c_int32(steps), C.c_void_p(table.data_ptr() if fill_table else 0),
-                                             C.c_void_p(xp.data_ptr()), C.c_int32(xp.shape[0]), C.c_void_p(gx.data_ptr()),
-                                             C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
-                                             C.c_void_p(L.stream_ptr())), "mdm_stem_cache_build")
+        with torch.cuda.device(dev):
+            L.check(L.lib().mdm_stem_cache_build(C.byref(pm.model), C.c_int32(steps), C.c_void_p(table.data_ptr() if fill_table else 0),
+                                                 C.c_void_p(xp.data_ptr()), C.c_int32(xp.shape[0]), C.c_void_p(gx.data_ptr()),
+                                                 C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
+                                                 C.c_void_p(L.stream_ptr())), "mdm_stem_cache_build")
         sc = L.StemCache()
         sc.time_table, sc.gx, sc.steps = table.data_ptr(), gx.data_ptr(), steps
         return {"sc": sc, "keep": (table, gx)}
@@ -339,6 +348,8 @@ class MotionTransformer(nn.Module):
                 workspace: Optional[torch.Tensor] = None):
         if not x.is_cuda:
             raise L.MdmError("MotionTransformer.forward needs GPU tensors: the denoiser runs on HIP kernels only")
+        if x.device != self.device:
+            raise L.MdmError(f"input on {x.device} but the model (packed weights, workspace) lives on {self.device}")
         B, T, Fe = x.shape
         if Fe != self.input_feats:
             raise ValueError(f"expected {self.input_feats} features, got {Fe}")
@@ -365,14 +376,19 @@ class MotionTransformer(nn.Module):
             raise ValueError("workspace too small for this (B, T, N)")
         if out is None:
             out = torch.empty((B, T, Fe), dtype=torch.float32, device=dev)
-        fr = forced_routing.to(device=dev, dtype=torch.int32).contiguous() if forced_routing is not None else None
+        fr = None
+        if forced_routing is not None:
+            fr = forced_routing.to(device=dev, dtype=torch.int32).contiguous()
+            if fr.numel() and (int(fr.min()) < 0 or int(fr.max()) >= self.moe_num_experts):  # test hook, host-checked
+                raise ValueError("forced_routing holds expert indices outside [0, moe_num_experts)")
         tr = torch.zeros((2 * self.num_layers, 4, B * T, self.latent_dim), dtype=torch.float32, device=dev) if trace else None
-        L.check(L.lib().mdm_denoiser_forward(
-            C.byref(pm.model), C.byref(tcache["tc"]), C.c_void_p(x.data_ptr()), C.c_void_p(ts.data_ptr()),
-            C.c_void_p(ln.data_ptr()), C.c_void_p(xp.data_ptr()), C.c_int32(B), C.c_int32(T), C.c_void_p(out.data_ptr()),
-            C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(L.ptr(fr)), C.c_void_p(L.ptr(tr)),
-            C.byref(stem_cache["sc"]) if stem_cache is not None else None,
-            C.c_int32(self.precision), C.c_void_p(L.stream_ptr())), "mdm_denoiser_forward")
+        with torch.cuda.device(dev):
+            L.check(L.lib().mdm_denoiser_forward(
+                C.byref(pm.model), C.byref(tcache["tc"]), C.c_void_p(x.data_ptr()), C.c_void_p(ts.data_ptr()),
+                C.c_void_p(ln.data_ptr()), C.c_void_p(xp.data_ptr()), C.c_int32(B), C.c_int32(T), C.c_void_p(out.data_ptr()),
+                C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_void_p(L.ptr(fr)), C.c_void_p(L.ptr(tr)),
+                C.byref(stem_cache["sc"]) if stem_cache is not None else None,
+                C.c_int32(self.precision), C.c_void_p(L.stream_ptr())), "mdm_denoiser_forward")
         if trace:
             return out, tr
         return out

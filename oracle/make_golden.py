@@ -256,6 +256,82 @@ def case_loops(name, cfg, B, T, N, wseed, iseed, steps_cfg, steps_ddim):
     print(f"{name}: cfg final absmax {out['cfg/final'].abs().max():.4f}")
 
 
+def caption_embedding(caption: str, N: int, Dt: int, seed: int):
+    """Stub text embedding of ONE caption: N token rows (what a text encoder would return for it), a function of the string."""
+    return synth.uniform_pm1((N, Dt), "cap." + caption, seed) * (3.0 ** 0.5)
+
+
+def case_trainer_generate(name, cfg, captions, m_lens, batch_size, N_cond, N_uncond, wseed, iseed, steps, cfg_scale):
+    """The reference's own DDPMTrainer.generate (trainers/ddpm_trainer.py:145-199) on the tiny model: captions -> stub text
+    embeddings (N_cond tokens per caption, N_uncond for the empty caption: a real tokenizer pads "" to fewer tokens than the
+    captions, and the uncond forward re-encodes [""] * B every step, gaussian_diffusion.py:1059-1062), m_lens, queued noise
+    -> the list generate() returns.  Pins the whole trainer call: T = min(m_lens.max(), num_frames), batching by
+    batch_size, clip_denoised=False, cfg_scale from args, x_T = th.randn(*shape) and randn_like per step."""
+    import types
+    with contextlib.redirect_stdout(io.StringIO()):
+        import trainers.ddpm_trainer as RTr
+    m, D = build_reference(cfg, wseed)
+    Dt, Fe = cfg["text_latent_dim_arg"], cfg["input_feats"]
+    eph = synth.synth_ephemerals(D, Dt, cfg["num_layers"], wseed)
+    xo_u1 = caption_embedding("", N_uncond, Dt, iseed)
+
+    class _Enc(nn.Module):
+        def forward(self, text, device):
+            if all(t == "" for t in text):
+                xo = xo_u1[None].expand(len(text), -1, -1).contiguous()
+            else:
+                xo = torch.stack([caption_embedding(t, N_cond, Dt, iseed) for t in text])
+            return xo.mean(dim=1), xo
+
+    m.text_encoder = _Enc()
+    args = types.SimpleNamespace(device=torch.device("cpu"), diffusion_steps=steps, is_train=False, cfg_scale=cfg_scale)
+    tr = RTr.DDPMTrainer(args, m)
+    m_lens_t = torch.tensor(m_lens)
+    # noise queues in the order generate() consumes them: per batch, x_T then one randn_like per step
+    nb = (len(captions) + batch_size - 1) // batch_size
+    xT, step_noise = [], []
+    for k in range(nb):
+        lo, hi = k * batch_size, min((k + 1) * batch_size, len(captions))
+        T = min(int(m_lens_t[lo:hi].max()), cfg["num_frames"])
+        xT.append(synth.uniform_pm1((hi - lo, T, Fe), f"gen.xT.{k}", iseed) * (3.0 ** 0.5))
+        step_noise.append([synth.uniform_pm1((hi - lo, T, Fe), f"gen.noise.{k}.{i}", iseed) * (3.0 ** 0.5) for i in range(steps)])
+    flat = [n for k in range(nb) for n in step_noise[k]]
+    orig_randn = torch.randn
+    qi = [0]
+
+    def randn(*shape, **kw):
+        x = xT[qi[0]]
+        qi[0] += 1
+        assert tuple(shape) == tuple(x.shape), (shape, x.shape)
+        return x.clone()
+
+    traj = []
+    orig_step = tr.diffusion.p_sample_with_cfg
+
+    def rec(*a, **k):
+        o = orig_step(*a, **k)
+        traj.append(o["sample"].clone())
+        return o
+
+    tr.diffusion.p_sample_with_cfg = rec
+    torch.randn = randn
+    try:
+        with _EphemeralQueue(eph), _NoiseQueue(flat), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            outs = tr.generate(list(captions), m_lens_t, Fe, batch_size=batch_size)
+    finally:
+        torch.randn = orig_randn
+    assert len(outs) == len(captions) and qi[0] == nb
+    out = {"m_lens": m_lens_t}
+    for i, o in enumerate(outs):
+        out[f"out/{i}"] = o
+    out["traj0/idx"] = torch.tensor([0, steps // 2, steps - 1])
+    out["traj0"] = torch.stack([traj[i] for i in (0, steps // 2, steps - 1)])  # first batch's x_t after those steps
+    meta = dict(cfg=cfg, captions=list(captions), batch_size=batch_size, N_cond=N_cond, N_uncond=N_uncond, wseed=wseed,
+                iseed=iseed, steps=steps, cfg_scale=cfg_scale, latent_dim=D, text_latent_dim=Dt)
+    save(name, out, meta)
+    print(f"{name}: {len(outs)} samples, shapes {[tuple(o.shape) for o in outs]}, absmax {max(float(o.abs().max()) for o in outs):.4f}")
+
+
 def case_layout():
     lay = {}
     for tag, kw in {
@@ -396,6 +472,10 @@ def main():
     if "--moe-loss-only" in sys.argv:
         case_moe_loss()
         return
+    if "--trainer-only" in sys.argv:
+        case_trainer_generate("trainer_generate", cfgd(64, 128, 4, 32, 4, 1, frames=16), ["a person walks", "someone jumps", "a man sits down"],
+                              [16, 12, 10], 2, 6, 4, wseed=18, iseed=28, steps=25, cfg_scale=2.5)
+        return
     if "--loops-only" not in sys.argv:
         case_text_head()
         case_motion_post()
@@ -409,6 +489,8 @@ def main():
         case_forward("fwd_big_dims", cfgd(512, 1024, 4, 256, 8, 1, size="big"), B=2, T=8, N=5, wseed=15, iseed=25, trace_level="main")
         case_forward("fwd_tools_shape", cfgd(512, 256, 4, 128, 4, 2), B=2, T=12, N=7, wseed=16, iseed=26, trace_level="main")
     case_loops("loops_tiny", cfgd(64, 128, 4, 32, 4, 1, frames=16), B=2, T=16, N=6, wseed=17, iseed=27, steps_cfg=25, steps_ddim=25)
+    case_trainer_generate("trainer_generate", cfgd(64, 128, 4, 32, 4, 1, frames=16), ["a person walks", "someone jumps", "a man sits down"],
+                          [16, 12, 10], 2, 6, 4, wseed=18, iseed=28, steps=25, cfg_scale=2.5)
 
 
 if __name__ == "__main__":

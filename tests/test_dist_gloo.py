@@ -18,10 +18,16 @@ def _free_port():
     return p
 
 
-def _fake_sampler(local_shape, kw, x_T, step_noise):
-    # a stand-in "denoising loop": per-sample arithmetic only (samples never interact)
-    x = x_T.clone()
-    for n in step_noise:
+def _fake_sampler(local_shape, kw, seed, first):
+    # a stand-in "denoising loop" on the CPU: per-sample arithmetic only (samples never interact), noise from
+    # the counter-based generator exactly as the HIP sampler keys it: (seed, first + row, timestep | x_T stream, element)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import philox_ref as P
+    b, per = local_shape[0], int(torch.tensor(local_shape[1:]).prod())
+    x = torch.from_numpy(P.normal(per, b, first, seed, P.STREAM_XT)).view(local_shape)
+    for t in (2, 1, 0):
+        n = torch.from_numpy(P.normal(per, b, first, seed, t)).view(local_shape)
         x = 0.9 * x + 0.1 * n * kw["length"].view(-1, 1, 1).float() + kw["xf_proj"].sum(-1).view(-1, 1, 1)
     return x
 
@@ -34,7 +40,7 @@ def _worker(rank, world, port, B, out_path):
     dmod = pkg("dist")
     kw = {"length": torch.arange(B) + 3, "xf_proj": torch.arange(B * 2, dtype=torch.float32).view(B, 2),
           "text": [f"t{i}" for i in range(B)], "scalar": 5}
-    y = dmod.sample_sharded(_fake_sampler, (B, 4, 3), kw, seed=7, steps_with_noise=3)
+    y = dmod.sample_sharded(_fake_sampler, (B, 4, 3), kw, seed=7)
     if rank == 0:
         torch.save(y, out_path)
     dist.barrier()
@@ -46,7 +52,7 @@ def test_sharded_sampling_is_world_size_invariant(tmp_path, B):
     dmod = pkg("dist")
     kw = {"length": torch.arange(B) + 3, "xf_proj": torch.arange(B * 2, dtype=torch.float32).view(B, 2),
           "text": [f"t{i}" for i in range(B)], "scalar": 5}
-    single = dmod.sample_sharded(_fake_sampler, (B, 4, 3), kw, seed=7, steps_with_noise=3)
+    single = dmod.sample_sharded(_fake_sampler, (B, 4, 3), kw, seed=7)
     out = str(tmp_path / "y.pt")
     mp.spawn(_worker, args=(2, _free_port(), B, out), nprocs=2, join=True)
     assert torch.equal(torch.load(out), single)

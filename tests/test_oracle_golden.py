@@ -138,3 +138,56 @@ def test_motion_post_oracle_matches_reference_golden():
         assert np.array_equal(j, g[f"joints/{b}"].numpy()), b
         r = MR.motion_to_joints(g["motion"][b, :n], g["mean"].numpy(), g["std"].numpy(), 22, 0.0)
         assert np.array_equal(r, g[f"joints_raw/{b}"].numpy()), b
+
+
+def test_two_forward_cfg_with_different_token_counts_matches_reference_trainer():
+    """The oracle's CFG loop with cond / uncond text of DIFFERENT token counts against the golden produced by the reference's
+    own DDPMTrainer.generate (trainers/ddpm_trainer.py:145-199): the path a real tokenizer takes ("" -> fewer tokens)."""
+    g, meta = load_golden("trainer_generate")
+    sd, eph, proj, mcfg = golden_state(meta)
+    synth = pkg("synth")
+    Dt, Fe, steps, bs = meta["text_latent_dim"], meta["cfg"]["input_feats"], meta["steps"], meta["batch_size"]
+    caps, lens = meta["captions"], g["m_lens"]
+    tb = DR.Tables(DR.linear_betas(steps))
+
+    def emb(c, N):
+        return synth.uniform_pm1((N, Dt), "cap." + c, meta["iseed"]) * (3.0 ** 0.5)
+
+    i_out = 0
+    for k in range((len(caps) + bs - 1) // bs):
+        lo, hi = k * bs, min((k + 1) * bs, len(caps))
+        B = hi - lo
+        T = min(int(lens[lo:hi].max()), meta["cfg"]["num_frames"])
+        xo_c = torch.stack([emb(c, meta["N_cond"]) for c in caps[lo:hi]])
+        xo_u = emb("", meta["N_uncond"])[None].expand(B, -1, -1).contiguous()
+
+        def model(x, t, cond, xo_c=xo_c, xo_u=xo_u, ln=lens[lo:hi]):
+            xo = xo_c if cond else xo_u
+            return R.denoiser_forward(sd, mcfg, x, t, ln, xo.mean(1), xo, eph, proj)
+
+        x_T = synth.uniform_pm1((B, T, Fe), f"gen.xT.{k}", meta["iseed"]) * (3.0 ** 0.5)
+        nz = [synth.uniform_pm1((B, T, Fe), f"gen.noise.{k}.{i}", meta["iseed"]) * (3.0 ** 0.5) for i in range(steps)]
+        keep = []
+        with torch.no_grad():
+            y = DR.cfg_ddpm_loop(model, tb, x_T, nz, cfg_scale=meta["cfg_scale"], keep=keep)
+        if k == 0:
+            for j, i in enumerate(g["traj0/idx"].tolist()):
+                assert rel_inf(keep[i], g["traj0"][j]) < 2e-4, i
+        for b in range(B):
+            assert rel_inf(y[b], g[f"out/{i_out}"]) < 2e-4, i_out
+            i_out += 1
+
+
+def test_philox_known_answers():
+    """oracle/philox_ref.py (the restatement of csrc/noise.hip) against the published Random123 known-answer vectors of
+    philox4x32-10 (kat_vectors: zero, all-ones and the pi-digits counter/key)."""
+    import philox_ref as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = P.philox4x32_10(np.array(ctr, dtype=np.uint32), key[0], key[1])
+        assert tuple(int(v) for v in got) == want
+    z = P.normal(4096, 8, 3, 99, 5)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1) < 0.02
+    assert np.array_equal(P.normal(4096, 2, 5, 99, 5), z[2:4])   # rows are a function of the GLOBAL sample index only
