@@ -734,7 +734,13 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
   {
     LinOpts o;
     o.R1 = m->seq_emb, o.r1_mod = T;
-    MDM_TRY(linear(c, act_f32(x), Mfull, m->feats, m->joint, m->joint_b, D, w.h0, c.bf ? w.h016 : nullptr, o));
+    // the root of the residual stream (and of the U's skip connection): always the bf16x3 arithmetic -- 3.4 GFLOP, K = 263.
+    // Measured at B = 32 / T = 196 / L = 4, fp16 mode, free routing: 1679 -> 596 of 75264 routing decisions differ from the
+    // fp32-grade run, median frame error 4.7e-3 -> 1.8e-3 (tools/mode_compare.py; knob 31 restores the single bf16 pass).
+    // The same treatment of down / up / the stem GEMMs bought another 14 % for +0.2 ms per step: not taken.
+    Ctx cj = c;
+    if (g_bf16_variant != 31) cj.prec = 3;
+    MDM_TRY(linear(cj, act_f32(x), Mfull, m->feats, m->joint, m->joint_b, D, w.h0, c.bf ? w.h016 : nullptr, o));
   }
   // Conv1d(k=2,s=2) == Linear over pairs of frames                  (:332-337)
   MDM_TRY(linear(c, c.bf ? act_bf16(w.h016) : act_f32(w.h0), Mlow, 2 * D, m->down, m->down_b, D, w.xa,

@@ -19,7 +19,7 @@ STYLE_SLOTS = ("local_style", "global_style", "cross_style", "ffn_style")
 
 # Weights that are always packed as bf16 hi + lo planes: they are multiplied with fp32 activations by the register-staged
 # kernel (csrc/gemm.hip) in every mode -- the per-loop stem / text caches are always built in the bf16x3 arithmetic, and
-# joint_embed reads the fp32 motion tensor itself.
+# joint_embed reads the fp32 motion tensor itself (the root of the residual stream: fp32-grade in every mode).
 _ALWAYS_X3 = ("tmlp0", "tmlp2", "te0", "te2", "tproj", "gf_time", "gf_text", "text_proj", "joint")
 _ALWAYS_X3_LAYER = ("ca_k", "ca_v", "sd_k", "sd_v")
 _MLP_LAYER = ("w1", "w2", "sd_f1", "sd_f2")  # the MFMA-bound GEMMs: expert MLPs and the 4x FFN

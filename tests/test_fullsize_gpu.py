@@ -44,7 +44,7 @@ def _oracle(host, x, t, length, xf_proj, xf_out):
         return R.denoiser_forward(host["sd"], host["mcfg"], x, t, length, xf_proj, xf_out, host["eph"], host["proj"])
 
 
-@pytest.mark.parametrize("precision,tol", [(3, 1e-3), (1, None)])
+@pytest.mark.parametrize("precision,tol", [(3, 1e-3)])  # the other modes: error + flip budgets in test_round2_gpu.py
 def test_configs1_one_sample_of_the_full_batch_matches_the_oracle(precision, tol):
     B, T = 32, 196
     m, host, (x, length, xf_proj, xf_out) = _build(8, B, T, precision)
