@@ -113,6 +113,10 @@ typedef struct MdmMlpDesc {
   uint16_t* C16; /* optional 16-bit copy */
   int64_t ldc;
   int32_t h16;   /* MDM_H16_*: format of X, w1, w2 and C16 (0 = bf16) */
+  /* optional fragment-major copies of w1 / w2 (same 16-bit format, built by packing.py: mlp_fragment_major): when both
+   * are set and Din == Dout == 512 the second-generation kernel (csrc/mlp2.hip) runs; group stride F*Din / Dout*F elements */
+  const uint16_t* w1f;
+  const uint16_t* w2f;
 } MdmMlpDesc;
 
 int mdm_fused_mlp(const MdmMlpDesc* desc, void* stream);
@@ -163,6 +167,7 @@ typedef struct MdmLayer { /* MoEExtendedDecoderLayer, transformer.py:17-64 */
   const float *moe_ln_w[2], *moe_ln_b[2], *gate_w[2], *gate_b[2];
   MdmPacked w1; /* [2*E*F, D] */
   MdmPacked w2; /* [2*E*D, F] */
+  const uint16_t *w1f, *w2f; /* optional fragment-major copies for csrc/mlp2.hip (16-bit expert modes, D == 512), or NULL */
   const float *b1, *b2;
   float *usage[2], *importance[2]; /* expert_usage / expert_importance buffers, updated in place; may be NULL */
   MdmStyle ffn_style;

@@ -47,7 +47,7 @@ class MlpDesc(C.Structure):
                 ("w2", C.c_void_p), ("ldw2", C.c_int64), ("w2_gs", C.c_int64), ("b2", C.c_void_p), ("b2_gs", C.c_int64),
                 ("rowscale", C.c_void_p), ("R1", C.c_void_p), ("ldr1", C.c_int64), ("r1_scale", C.c_float),
                 ("R2", C.c_void_p), ("ldr2", C.c_int64), ("C", C.c_void_p), ("C16", C.c_void_p), ("ldc", C.c_int64),
-                ("h16", C.c_int32)]
+                ("h16", C.c_int32), ("w1f", C.c_void_p), ("w2f", C.c_void_p)]
 
 
 class Packed(C.Structure):
@@ -77,7 +77,7 @@ class Layer(C.Structure):
                 ("ca_q_b", C.c_void_p), ("ca_k_b", C.c_void_p), ("ca_v_b", C.c_void_p), ("ca_gvec", C.c_void_p),
                 ("ca_style", Style),
                 ("moe_ln_w", _P2), ("moe_ln_b", _P2), ("gate_w", _P2), ("gate_b", _P2), ("w1", Packed), ("w2", Packed),
-                ("b1", C.c_void_p), ("b2", C.c_void_p), ("usage", _P2), ("importance", _P2), ("ffn_style", Style),
+                ("w1f", C.c_void_p), ("w2f", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p), ("usage", _P2), ("importance", _P2), ("ffn_style", Style),
                 ("sd_q", Packed), ("sd_k", Packed), ("sd_v", Packed), ("sd_out", Packed), ("sd_f1", Packed),
                 ("sd_f2", Packed), ("sd_q_b", C.c_void_p), ("sd_k_b", C.c_void_p), ("sd_v_b", C.c_void_p),
                 ("sd_out_b", C.c_void_p), ("sd_ln_w", C.c_void_p), ("sd_ln_b", C.c_void_p), ("sd_f1_b", C.c_void_p),

@@ -54,5 +54,7 @@ bool gemm_bf16_256_eligible(const GemmArgs& a);
 int gemm_bf16_256(const GemmArgs& a, hipStream_t stream);  // gemm4.hip: 256x256 tile, 8 waves
 bool fused_mlp_supported(const MdmMlpDesc& a);
 int fused_mlp(const MdmMlpDesc& a, hipStream_t stream);  // mlp.hip: Linear-GELU-Linear, hidden layer kept in LDS
+bool fused_mlp2_supported(const MdmMlpDesc& a);
+int fused_mlp2(const MdmMlpDesc& a, hipStream_t stream);  // mlp2.hip: hidden layer kept in REGISTERS (Din = Dout = 512)
 
 }  // namespace mdm

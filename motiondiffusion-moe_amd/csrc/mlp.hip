@@ -249,7 +249,12 @@ bool fused_mlp_supported(const MdmMlpDesc& a) {
   return true;
 }
 
+extern int g_bf16_variant;
+
 int fused_mlp(const MdmMlpDesc& a, hipStream_t stream) {
+  // The second generation (hidden layer in registers, csrc/mlp2.hip) is correct but measured SLOWER than this kernel (215 vs
+  // 179 us at 50176 rows; knock-outs in DESIGN.md section 6): it runs only on request (knob 35, or 41..44 for its knock-outs)
+  if ((g_bf16_variant == 35 || (g_bf16_variant >= 41 && g_bf16_variant <= 44)) && fused_mlp2_supported(a)) return fused_mlp2(a, stream);
   if (!a.X || !a.w1 || !a.w2 || (!a.C && !a.C16)) return MDM_ERR_ARG;
   if (!fused_mlp_supported(a)) return MDM_ERR_UNSUPPORTED;
   constexpr int smem = HC_B + NST * STAGE_B;  // 163840

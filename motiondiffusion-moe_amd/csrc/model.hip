@@ -335,6 +335,7 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
   f.rowscale = w.rowscale, f.r1_scale = 1.f;
   f.C = w.y2, f.ldc = D;
   f.h16 = c.h16;
+  f.w1f = l.w1f, f.w2f = l.w2f;
   const bool h = c.bf || c.mix;  // 16-bit expert operands
   if (h && g_bf16_variant != 21 && fused_mlp_supported(f)) {  // variant 21: two-GEMM chain, for A/B runs
     // throughput mode: both expert GEMMs in one kernel, hidden activations stay in LDS (switch_moe.py:19-25,104-109)

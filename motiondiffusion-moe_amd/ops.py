@@ -111,10 +111,25 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
     return out.reshape(*x.shape[:-1], w.N)
 
 
+def mlp_fragment_major(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype):
+    """Fragment-major 16-bit copies of expert weights for csrc/mlp2.hip (Din = Dout = 512, F % 64 == 0):
+    w1 (G, F, D) -> [G][chunk c = F/32][k-step s = D/16][lane = 32 h + r][8]   with element  w1[g][32c + r][16s + 8h + j];
+    w2 (G, Dout, F) -> [G][chunk c][n-tile t = Dout/32][k-step s2 < 2][lane = 32 h + r][8]   with element
+    w2[g][32t + r][32c + 16 s2 + 8 (j >> 2) + 4 h + (j & 3)]: the k order inside a fragment follows the register -> row
+    map of a 32x32 MFMA accumulator, so the GELU'd hidden tile feeds phase 2 without leaving registers.
+    Every 1-KiB run is one MFMA A-fragment of one wave: what one LDS-DMA instruction moves."""
+    G, F, D = w1.shape
+    Dout = w2.shape[1]
+    assert w2.shape == (G, Dout, F) and F % 32 == 0 and D % 16 == 0 and Dout % 32 == 0
+    a = w1.reshape(G, F // 32, 32, D // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)            # g, c, s, h, r, j
+    b = w2.reshape(G, Dout // 32, 32, F // 32, 2, 2, 2, 4).permute(0, 3, 1, 4, 6, 2, 5, 7)  # g, c, t, s2, h, r, q, i
+    return a.to(dtype).contiguous().reshape(G, F * D), b.to(dtype).contiguous().reshape(G, Dout * F)
+
+
 def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w2: PackedWeight,
               b2: Optional[torch.Tensor], *, gather=None, goff=None, rowscale=None, r1=None, r1_scale: float = 1.0,
               r2=None, rows: Optional[int] = None, out: Optional[torch.Tensor] = None,
-              out16: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out16: Optional[torch.Tensor] = None, frag=None) -> torch.Tensor:
     """y = (GELU(x w1^T + b1) w2^T + b2) * rowscale + r1_scale * r1 + r2 with the hidden layer kept on chip (mlp.hip).
     ``goff`` (int32 [G+1], device) selects grouped mode: w1 / w2 / b1 / b2 then carry a leading group axis."""
     L.require_cuda(x16)
@@ -137,6 +152,9 @@ def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w
     d.w1, d.ldw1, d.b1 = w1.hi.data_ptr(), w1.Kp, L.ptr(b1)
     d.w2, d.ldw2, d.b2 = w2.hi.data_ptr(), w2.Kp, L.ptr(b2)
     d.rowscale = L.ptr(rowscale)
+    if frag is not None:  # (w1f, w2f) from mlp_fragment_major: selects the second-generation kernel when the shape fits
+        assert frag[0].dtype == x16.dtype and frag[1].dtype == x16.dtype
+        d.w1f, d.w2f = frag[0].data_ptr(), frag[1].data_ptr()
     d.r1_scale = r1_scale
     if r1 is not None:
         d.R1, d.ldr1 = r1.data_ptr(), r1.stride(0)

@@ -77,3 +77,52 @@ def test_unsupported_shapes_are_refused():
     pw2 = ops.PackedWeight(_rand(512, 256, seed=3), with_lo=False)
     with pytest.raises(L.MdmError):
         ops.fused_mlp(x16, pw1, None, pw2, None)  # Din % 64 != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("sizes,F", [([130, 0, 257, 1, 128], 1024), ([3136] * 4, 1024), ([64, 700], 256)])
+def test_gen2_registers_resident_hidden_layer(dtype, sizes, F):
+    """Second-generation fused expert MLP (csrc/mlp2.hip: hidden layer kept in registers, fragment-major weight stream):
+    grouped / gathered / ragged / empty groups, both 16-bit formats, fp32 and 16-bit outputs, against the fp64 reference
+    with the same operand rounding, and against the first-generation kernel (knob 34) on the same inputs."""
+    L, ops = pkg("_lib"), pkg("ops")
+    Din, Dout, G, S = 512, 512, len(sizes), 900
+    fmt = "f16" if dtype == torch.float16 else "bf16"
+    M = sum(sizes)
+    goff = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
+    src = _rand(S, Din, seed=21).to(dtype)
+    g = torch.Generator(device="cpu").manual_seed(22)
+    gather = torch.randint(0, S, (M,), generator=g, dtype=torch.int32).cuda()
+    w1, b1 = _rand(G, F, Din, seed=23, scale=Din ** -0.5), _rand(G, F, seed=24, scale=0.1)
+    w2, b2 = _rand(G, Dout, F, seed=25, scale=F ** -0.5), _rand(G, Dout, seed=26, scale=0.1)
+    rs = _rand(M, seed=27).abs()
+    pw1, pw2 = ops.PackedWeight(w1, fmt=fmt), ops.PackedWeight(w2, fmt=fmt)
+    frag = ops.mlp_fragment_major(w1, w2, dtype)
+    out = torch.full((M + 3, Dout), 7.0, device="cuda")
+    out16 = torch.zeros((M + 3, Dout), dtype=dtype, device="cuda")
+    L.lib().mdm_set_gemm_variant(35)  # gen2 is opt-in (measured slower than gen1: DESIGN.md section 6)
+    try:
+        ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out=out, out16=out16, frag=frag)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    x = src[gather.long()]
+
+    def rd(t):
+        return t.to(dtype).double()
+
+    ref = torch.empty(M, Dout, dtype=torch.float64, device="cuda")
+    o = 0
+    for e, n in enumerate(sizes):
+        h = torch.nn.functional.gelu(x[o:o + n].double() @ rd(w1[e]).T + b1[e].double())
+        ref[o:o + n] = (rd(h.float()) @ rd(w2[e]).T + b2[e].double()) * rs[o:o + n, None].double()
+        o += n
+    e32 = rel_inf(out[:M].cpu(), ref.float().cpu())
+    e16 = rel_inf(out16[:M].float().cpu(), ref.float().cpu())
+    old = torch.empty((M, Dout), device="cuda")
+    ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out=old, frag=frag)
+    d = rel_inf(out[:M].cpu(), old.cpu())
+    print(f"gen2 {fmt} sizes {sizes[:3]}.. F {F}: vs fp64 {e32:.2e} (16-bit out {e16:.2e}), vs gen1 {d:.2e}")
+    tol = 3e-3 if dtype == torch.bfloat16 else 6e-4
+    assert e32 < tol and e16 < 4 * tol and d < 2 * tol
+    assert torch.all(out[M:] == 7.0) and torch.all(out16[M:] == 0)
+    assert not torch.equal(out[:M], old)  # the knob really selects the other kernel
