@@ -27,11 +27,16 @@ CONFIGS = {
                    model_size="small"), 0.9012e12, 0.338e12),
     "big": (dict(latent_dim=512, ff_size=1024, num_layers=4, num_heads=4, text_latent_dim=256, moe_num_experts=8,
                  model_size="big"), 3.5926e12, 1.349e12),
+    # configs[4]: big, 16 experts, top-2, fp8 expert GEMMs (run with --precision 5 --batch 8: B=64 over 8 GPUs)
+    "big16": (dict(latent_dim=512, ff_size=1024, num_layers=4, num_heads=4, text_latent_dim=256, moe_num_experts=16,
+                   model_size="big"), 3.5938e12, 1.349e12),
 }
 # dense bf16 / fp16 MFMA peak (same rate); the bf16x3 mode issues 3 MFMAs per product; the mixed mode issues 3 per product
 # except in the expert MLPs + 4x FFN (52 % of the FLOPs at the small config: SURVEY.md section 8a): blended 1 / (0.48*3 + 0.52)
-PEAK = {1: 2.5e15, 2: 2.5e15, 3: 2.5e15 / 3, 4: 2.5e15 / (0.48 * 3 + 0.52)}
-DTYPE = {1: "bf16", 2: "f16", 3: "bf16x3(fp32-grade)", 4: "mixed(bf16x3 + f16 expert/FFN GEMMs)"}
+# precision 5 (fp8 expert GEMMs): blended by FLOP share as SURVEY.md section 8(d) prescribes: the MoE FFN's 37.5 % at the 5 PF
+# dense fp8 rate, the rest at 2.5 PF -> 1 / (0.375 / 5 + 0.625 / 2.5) = 3.08 PF
+PEAK = {1: 2.5e15, 2: 2.5e15, 3: 2.5e15 / 3, 4: 2.5e15 / (0.48 * 3 + 0.52), 5: 1.0 / (0.375 / 5.0e15 + 0.625 / 2.5e15)}
+DTYPE = {1: "bf16", 2: "f16", 3: "bf16x3(fp32-grade)", 4: "mixed(bf16x3 + f16 expert/FFN GEMMs)", 5: "f16 + fp8(e4m3) expert GEMMs"}
 
 
 def build_model(cfg_name, device, precision, B, T, N, seed=0):
@@ -289,10 +294,12 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="small", choices=list(CONFIGS))
-    ap.add_argument("--precision", type=int, default=2, choices=[1, 2, 3, 4],
+    ap.add_argument("--precision", type=int, default=2, choices=[1, 2, 3, 4, 5],
                     help="1 = bf16 MFMA, 2 = fp16 MFMA (default: same speed, 8x smaller error), 3 = bf16x3 fp32-grade, "
                          "4 = mixed (bf16x3 + fp16 expert/FFN GEMMs)")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-mode timing / error table")
+    ap.add_argument("--sampler", default="cfg", choices=["cfg", "ddim"],
+                    help="cfg = guided DDPM step (2 forwards batched; configs[1], [2]); ddim = DDIM step (1 forward; configs[3])")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
     ap.add_argument("--frames", type=int, default=196)
     ap.add_argument("--schedule", type=int, default=1000)
@@ -324,7 +331,7 @@ def main():
                                 model_mean_type=D_.ModelMeanType.EPSILON, model_var_type=D_.ModelVarType.FIXED_SMALL,
                                 loss_type=D_.LossType.MSE)
     kw = {"xf_proj": xf_proj.to(dev), "xf_out": xf_out.to(dev), "length": length.to(dev), "text": ["synthetic"] * B}
-    r = diff._runner(m, (B, T, 263), kw, dev, "cfg", a.cfg_scale, 0.0, False, not a.no_graph, a.streams)
+    r = diff._runner(m, (B, T, 263), kw, dev, a.sampler, a.cfg_scale, 0.0, False, not a.no_graph, a.streams)
     r.philox = (1234, dmod.shard_range(B * world, rank, world)[0])
     r._prepare()
     if r.use_graph:
@@ -373,29 +380,34 @@ def main():
     if rank == 0:
         _, flop_fwd, flop_moe = CONFIGS[a.config]
         scale = (B / 32.0) * (T / 196.0)
-        flop_step = 2.0 * flop_fwd * scale  # cond + uncond forwards
+        nfwd = 2.0 if a.sampler == "cfg" else 1.0
+        flop_step = nfwd * flop_fwd * scale  # cond + uncond forwards (CFG) or one forward (DDIM)
         ms = dt / a.steps * 1e3
         steps_per_s = a.steps / dt
         value = steps_per_s * world * (B / 32.0)
         achieved = flop_step / (dt / a.steps)
-        moe_dt, moe_flop = moe_block_rate(m, 2 * B, T, a.precision)
-        dom = expert_mlp_rate(m, 2 * B, T)
+        rows_b = (2 if a.sampler == "cfg" else 1) * B
+        moe_dt, moe_flop = moe_block_rate(m, rows_b, T, a.precision)
+        dom = expert_mlp_rate(m, rows_b, T)
         done[0] = 0
         r.t_dev.fill_(a.schedule - 1)
         live = probe_dominant_kernel(r, m) if not r.chunks else None  # single-stream steps only
-        modes = None if a.no_modes else mode_table(a, m, inputs, host, diff, kw, dev, a.precision, ms)
+        modes = None if (a.no_modes or a.sampler != "cfg" or a.config != "small") else mode_table(a, m, inputs, host, diff, kw, dev, a.precision, ms)
         traffic = None  # HBM-side bytes per step from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc) and (a.config, B, T, a.precision) == ("small", 32, 196, 1) and False:  # r01 passes: stale
             traffic = json.load(open(pmc))["total_bytes_per_step"]
+        cfgname = {"small": "configs[1]", "big": "configs[2]" if a.sampler == "cfg" else "configs[3]", "big16": "configs[4]"}[a.config]
+        stepdesc = (f"{a.schedule}-step DDPM with CFG {a.cfg_scale} (cond+uncond batched as {2 * B} rows)" if a.sampler == "cfg"
+                    else f"{a.schedule}-step DDIM (eta 0, one forward per step)")
+        workload = (f"{cfgname}: model_size={'small' if a.config == 'small' else 'big'}, num_experts={m.moe_num_experts}, B={B}/GPU, T={T}, {stepdesc}, N_text={N}, "
+                    f"hipGraph={'on' if r.graph is not None else 'off'}, streams={r.nstreams if r.chunks else 1}")
         line = {
             "metric": "denoising-steps/sec (B=32, T=196, 263-d, 8 experts)", "value": round(value, 3),
             "unit": "denoising-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[a.precision], "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if a.config == 'small' else 'configs[2]'}: model_size={a.config}, num_experts=8, B={B}/GPU, T={T}, "
-                                   f"{a.schedule}-step DDPM with CFG {a.cfg_scale} (cond+uncond batched as {2 * B} rows), "
-                                   f"N_text={N}, hipGraph={'on' if r.graph is not None else 'off'}, streams={r.nstreams if r.chunks else 1}",
+            "config": {"workload": workload,
                        "global_batch": B * world, "parallelism": f"batch-shard x{world}, weights replicated"},
             "sample_steps_per_s": round(steps_per_s * B * world, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK[a.precision] / 1e12,

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 enum { MDM_OK = 0, MDM_ERR_ARG = 1, MDM_ERR_LAUNCH = 2, MDM_ERR_UNSUPPORTED = 3 };
-enum { MDM_OP_F32_ROW = 0, MDM_OP_F32_KSTRIDE = 1, MDM_OP_BF16_ROW = 2 };
+enum { MDM_OP_F32_ROW = 0, MDM_OP_F32_KSTRIDE = 1, MDM_OP_BF16_ROW = 2, MDM_OP_FP8_ROW = 3 /* e4m3 bytes, csrc/gemm8.hip */ };
 enum { MDM_ACT_NONE = 0, MDM_ACT_GELU = 1, MDM_ACT_SILU = 2, MDM_ACT_FEAT = 3 };
 /* 16-bit operand / storage format of the single-pass MFMA kernels: bf16, or IEEE fp16 (same MFMA rate on gfx950, 8x finer
  * rounding, |x| <= 65504: used where the value range is known). */
@@ -34,8 +34,10 @@ enum { MDM_H16_BF16 = 1, MDM_H16_F16 = 2 };
  *   3  bf16x3 split products everywhere, fp32 activations (fp32-grade: the mode that meets the 1e-3 parity bar)
  *   4  mixed: bf16x3 for everything that feeds the fp32 residual stream and the MoE router, single fp16 pass for the
  *      MFMA-bound GEMMs only (expert MLPs, the 4x FFN of the text cross-attention block)
+ *   5  as 2, with the expert GEMMs on fp8 (e4m3) operands: activations quantised per row by the router kernel, weights per
+ *      output channel at pack time, block-scaled MFMA with unit block scales (csrc/gemm8.hip); BASELINE configs[4]
  * The packed weights must be in the matching format (packing.py: weight_format). */
-enum { MDM_PREC_BF16 = 1, MDM_PREC_F16 = 2, MDM_PREC_X3 = 3, MDM_PREC_MIXED = 4 };
+enum { MDM_PREC_BF16 = 1, MDM_PREC_F16 = 2, MDM_PREC_X3 = 3, MDM_PREC_MIXED = 4, MDM_PREC_FP8 = 5 };
 
 /* One GEMM operand: a [rows x K] matrix seen through a loader kind (see csrc/gemm.h). */
 typedef struct MdmOperand {
@@ -78,6 +80,12 @@ typedef struct MdmGemmDesc {
   int32_t feat_S, feat_rpt, feat_kslot;
   int32_t precision; /* 1 single pass, 3 bf16x3; 2 = single pass with fp16 operands (sets h16) */
   int32_t h16;       /* MDM_H16_*: format of BF16_ROW activation / weight planes in the single-pass kernels and of C16 */
+  /* fp8 GEMM (A.kind == W.kind == MDM_OP_FP8_ROW): acc * a_scale_u * a_scale[src row of m] * w_scale[n] (+ bias, act, ...) */
+  const float* a_scale; /* per activation row (indexed by the GATHERED source row), or NULL */
+  const float* w_scale; /* per output channel; grouped like bias (bias_bs), or NULL */
+  float a_scale_u;      /* uniform activation scale (1 by default) */
+  uint8_t* C8;          /* optional fp8 output e4m3(v * c8_scale), same ldc */
+  float c8_scale;
 } MdmGemmDesc;
 
 int mdm_gemm(const MdmGemmDesc* desc, void* stream);
@@ -125,13 +133,16 @@ int mdm_fused_mlp(const MdmMlpDesc* desc, void* stream);
  * lo may be NULL.  Weight packing happens once at load time (not on the hot path). */
 int mdm_pack_bf16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* hi, uint16_t* lo,
                   int64_t ld_dst, void* stream);
+/* fp32 [rows, K] -> e4m3 bytes [rows, ld_dst] (ld_dst multiple of 128, zero padded) + scales[rows] = amax / 448 */
+int mdm_pack_fp8(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint8_t* dst, int64_t ld_dst, float* scales,
+                 void* stream);
 /* same layout, one IEEE fp16 plane (MDM_H16_F16 weights of the single-pass kernels) */
 int mdm_pack_f16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* dst, int64_t ld_dst, void* stream);
 
 /* ---- packed weights of one denoiser (built once at load time by motiondiffusion-moe_amd/packing.py) ------------ */
 typedef struct MdmPacked { /* 16-bit planes of an fp32 [N,K] weight, K padded to ld (multiple of 32) */
   const uint16_t* hi; /* bf16 hi plane, or the fp16 plane of a weight packed for a single fp16 pass */
-  const uint16_t* lo; /* bf16 lo plane (bf16x3), NULL otherwise */
+  const uint16_t* lo; /* bf16 lo plane (bf16x3); for an fp8-packed weight (hi = e4m3 bytes): its per-row fp32 scales; else NULL */
   int64_t ld;
 } MdmPacked;
 

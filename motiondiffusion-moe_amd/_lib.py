@@ -11,12 +11,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDM_LIB") or os.path.join(_HERE, "libmdm_hip.so")  # MDM_LIB: A/B benchmarking of builds
 _lib = None
 
-OP_F32_ROW, OP_F32_KSTRIDE, OP_BF16_ROW = 0, 1, 2
+OP_F32_ROW, OP_F32_KSTRIDE, OP_BF16_ROW, OP_FP8_ROW = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_FEAT = 0, 1, 2, 3
 H16_BF16, H16_F16 = 1, 2  # MDM_H16_*
-PREC_BF16, PREC_F16, PREC_X3, PREC_MIXED = 1, 2, 3, 4  # MDM_PREC_*
-PRECISIONS = (PREC_BF16, PREC_F16, PREC_X3, PREC_MIXED)
-PREC_NAMES = {1: "bf16", 2: "f16", 3: "bf16x3(fp32-grade)", 4: "mixed(bf16x3 + f16 expert/FFN GEMMs)"}
+PREC_BF16, PREC_F16, PREC_X3, PREC_MIXED, PREC_FP8 = 1, 2, 3, 4, 5  # MDM_PREC_*
+PRECISIONS = (PREC_BF16, PREC_F16, PREC_X3, PREC_MIXED, PREC_FP8)
+PREC_NAMES = {1: "bf16", 2: "f16", 3: "bf16x3(fp32-grade)", 4: "mixed(bf16x3 + f16 expert/FFN GEMMs)",
+              5: "f16 + fp8(e4m3) expert GEMMs"}
 
 
 class MdmError(RuntimeError):
@@ -37,7 +38,9 @@ class GemmDesc(C.Structure):
                 ("out_scale", C.c_float), ("r1_scale", C.c_float), ("r1_mod", C.c_int32),
                 ("colscale", C.c_void_p), ("rowscale", C.c_void_p), ("R1", C.c_void_p), ("ldr1", C.c_int64),
                 ("R2", C.c_void_p), ("ldr2", C.c_int64), ("feat_len", C.c_void_p), ("feat_S", C.c_int32),
-                ("feat_rpt", C.c_int32), ("feat_kslot", C.c_int32), ("precision", C.c_int32), ("h16", C.c_int32)]
+                ("feat_rpt", C.c_int32), ("feat_kslot", C.c_int32), ("precision", C.c_int32), ("h16", C.c_int32),
+                ("a_scale", C.c_void_p), ("w_scale", C.c_void_p), ("a_scale_u", C.c_float), ("C8", C.c_void_p),
+                ("c8_scale", C.c_float)]
 
 
 class MlpDesc(C.Structure):
@@ -129,7 +132,7 @@ def lib():
 
 
 # every symbol include/mdm_hip.h declares (checked by tests/test_abi.py)
-EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_pack_bf16", "mdm_pack_f16", "mdm_workspace_bytes", "mdm_text_cache_build",
+EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_pack_bf16", "mdm_pack_f16", "mdm_pack_fp8", "mdm_workspace_bytes", "mdm_text_cache_build",
            "mdm_denoiser_forward", "mdm_stem_cache_build", "mdm_block_forward", "mdm_moe_ffn_forward", "mdm_dual_self_attn_forward", "mdm_linear_xattn_forward",
            "mdm_softmax_xattn_ffn_forward", "mdm_performer_attn_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
            "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_noise_normal", "mdm_text_head_workspace_bytes", "mdm_text_head_forward", "mdm_motion_postprocess", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant", "mdm_debug_stamps", "mdm_probe_enable", "mdm_probe_read", "mdm_route_dump"]

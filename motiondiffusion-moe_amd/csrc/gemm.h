@@ -22,6 +22,8 @@ inline GemmArgs gemm_defaults(int precision) {
   g.out_scale = 1.f;
   g.r1_scale = 1.f;
   g.precision = precision;
+  g.a_scale_u = 1.f;
+  g.c8_scale = 1.f;
   return g;
 }
 inline Operand op_f32(const float* p, int64_t ld) {
@@ -54,6 +56,10 @@ bool gemm_bf16_256_eligible(const GemmArgs& a);
 int gemm_bf16_256(const GemmArgs& a, hipStream_t stream);  // gemm4.hip: 256x256 tile, 8 waves
 bool fused_mlp_supported(const MdmMlpDesc& a);
 int fused_mlp(const MdmMlpDesc& a, hipStream_t stream);  // mlp.hip: Linear-GELU-Linear, hidden layer kept in LDS
+bool gemm_x3_dma_eligible(const GemmArgs& a);
+int gemm_x3_dma(const GemmArgs& a, hipStream_t stream);  // gemm3.hip: bf16x3 with LDS-DMA staged fp32 activations
+bool gemm_fp8_eligible(const GemmArgs& a);
+int gemm_fp8(const GemmArgs& a, hipStream_t stream);  // gemm8.hip: e4m3 operands, block-scaled MFMA K = 128
 bool fused_mlp2_supported(const MdmMlpDesc& a);
 int fused_mlp2(const MdmMlpDesc& a, hipStream_t stream);  // mlp2.hip: hidden layer kept in REGISTERS (Din = Dout = 512)
 

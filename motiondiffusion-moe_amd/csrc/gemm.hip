@@ -7,6 +7,8 @@
 
 namespace mdm {
 
+extern int g_bf16_variant;
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
@@ -358,6 +360,11 @@ int gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.precision == 2) a.precision = 1, a.h16 = MDM_H16_F16;  // "2" = single pass with fp16 operands
   if (a.h16 != MDM_H16_F16) a.h16 = MDM_H16_BF16;
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return MDM_OK;
+  if (a.A.kind == MDM_OP_FP8_ROW || a.W.kind == MDM_OP_FP8_ROW) {
+    if (a.a_scale_u == 0.f) a.a_scale_u = 1.f;  // zero-initialised descriptors
+    if (a.c8_scale == 0.f) a.c8_scale = 1.f;
+    return gemm_fp8(a, stream);
+  }
   if (a.K <= 0 || !a.A.p || !a.W.p || (!a.C && !a.C16)) return MDM_ERR_ARG;
   if (a.A.kind == OP_BF16_ROW) return gemm_bf16(a, stream);  // bf16 activations: throughput kernel (gemm2.hip)
   if (a.precision != 1 && a.precision != 3) return MDM_ERR_ARG;
@@ -368,6 +375,8 @@ int gemm(const GemmArgs& a_in, hipStream_t stream) {
   }
   if (a.A.kind == OP_BF16_ROW) return MDM_ERR_UNSUPPORTED;
   if (a.goff && (a.batch != 1 || a.ngroups <= 0)) return MDM_ERR_ARG;
+  // plain Linears of the fp32-grade mode: LDS-DMA staged bf16x3 kernel (gemm3.hip); knob 36 keeps the register-staged one
+  if (g_bf16_variant != 36 && gemm_x3_dma_eligible(a)) return gemm_x3_dma(a, stream);
   const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
   const int tn = (a.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);

@@ -14,7 +14,8 @@ struct MoeGateParams {
   const float* gate_w[2];  // (E, D) fp32
   const float* gate_b[2];  // (E)
   void* hn;                // (2, M, D) out: LN_b(x), fp32 or bf16
-  int hn_bf16;             // 0 = fp32, else the 16-bit format code (MDM_H16_*)
+  int hn_bf16;             // 0 = fp32, 1 / 2 = the 16-bit format code (MDM_H16_*), 3 = fp8 e4m3 rows + hn_scale
+  float* hn_scale;         // (2, M) per-row scales of the fp8 rows (amax / 448)
   int* top_idx;            // (2, M, 2)
   float* top_val;          // (2, M, 2)
   int* hist;               // [1024][32] per-block partial histograms (no atomics, no memset)

@@ -45,7 +45,7 @@ struct Work {
   float *xa, *xb, *h0, *t1, *t2, *t3, *t4, *t5, *qkv, *phi, *kvt, *scr, *f1, *hn, *hid, *y2;
   uint16_t *xa16, *xb16, *h016;
   int *top_idx, *perm, *pos4, *hist, *goff, *cursor, *len_low;
-  float *top_val, *rowscale, *uimp;
+  float *top_val, *rowscale, *uimp, *hn_scale;
   // stem (B rows)
   float *s_a, *s_b, *s_c, *emb, *e1, *sc, *gvtmp;
   // text cache scratch
@@ -72,6 +72,7 @@ Work carve(const MdmModel& m, int B, int T, int N, void* ws) {
   w.y2 = b.take<float>(4 * M * D);
   w.top_idx = b.take<int>(4 * M), w.top_val = b.take<float>(4 * M);
   w.perm = b.take<int>(4 * M), w.rowscale = b.take<float>(4 * M), w.pos4 = b.take<int>(4 * M);
+  w.hn_scale = b.take<float>(2 * M);
   w.hist = b.take<int>(1024 * 32), w.uimp = b.take<float>(1024 * 64), w.goff = b.take<int>(2 * m.E + 1), w.cursor = b.take<int>(2 * m.E);
   w.len_low = b.take<int>(B);
   const int64_t smax = Te > 2 * D ? Te : 2 * D;
@@ -93,6 +94,7 @@ struct Ctx {
   bool bf;          // throughput modes (precision 1 / 2): GEMM-only tensors are kept in 16 bits
   int h16;          // the 16-bit format of this run: MDM_H16_BF16 (precision 1, 3) or MDM_H16_F16 (precision 2, 4)
   bool mix;         // precision 4: fp32-grade flow, but expert MLPs + the 4x FFN run as ONE fp16 pass on 16-bit operands
+  bool fp8;         // precision 5: as 2, expert GEMMs on e4m3 operands (csrc/gemm8.hip)
   int B, S, N;      // batch, frames at this scale, text tokens
   int64_t M;        // B*S
   const int* len;   // lengths at this scale
@@ -107,8 +109,11 @@ bool use_bf16_acts(const MdmModel* m, int precision) {
 }
 // precision (include/mdm_hip.h: MDM_PREC_*) -> how this run computes; false = unsupported combination
 bool set_precision(Ctx& c, const MdmModel* m, int precision) {
-  c.mix = false, c.bf = false, c.h16 = MDM_H16_BF16;
+  c.mix = false, c.bf = false, c.fp8 = false, c.h16 = MDM_H16_BF16;
   switch (precision) {
+    case MDM_PREC_FP8:  // the fp16 throughput mode with fp8 expert GEMMs (K = D and K = F must be multiples of 128)
+      c.prec = 1, c.bf = use_bf16_acts(m, MDM_PREC_F16), c.h16 = MDM_H16_F16, c.fp8 = true;
+      return c.bf && m->D % 128 == 0 && m->F % 128 == 0;
     case MDM_PREC_BF16: c.prec = 1, c.bf = use_bf16_acts(m, precision); return true;
     case MDM_PREC_F16:  // fp16 weight planes are only readable by the 16-bit-activation kernels
       c.prec = 1, c.bf = use_bf16_acts(m, precision), c.h16 = MDM_H16_F16;
@@ -322,7 +327,7 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     p.gate_w[b] = l.gate_w[b], p.gate_b[b] = l.gate_b[b];
     p.usage[b] = l.usage[b], p.importance[b] = l.importance[b];
   }
-  p.hn = w.hn, p.hn_bf16 = fmt_mlp(c), p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.uimp = w.uimp, p.forced_idx = forced;
+  p.hn = w.hn, p.hn_bf16 = c.fp8 ? 3 : fmt_mlp(c), p.hn_scale = w.hn_scale, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.uimp = w.uimp, p.forced_idx = forced;
   MDM_TRY(moe_route(x, c.M, D, E, p, w.goff, w.cursor, w.perm, w.rowscale, w.pos4, c.s));
   if (route_out && hipMemcpyAsync(route_out, w.top_idx, 4 * c.M * sizeof(int32_t), hipMemcpyDeviceToDevice, c.s) != hipSuccess)
     return MDM_ERR_LAUNCH;
@@ -337,6 +342,35 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
   f.h16 = c.h16;
   f.w1f = l.w1f, f.w2f = l.w2f;
   const bool h = c.bf || c.mix;  // 16-bit expert operands
+  if (c.fp8) {
+    // fp8 experts (switch_moe.py:19-25,104-109 on e4m3 operands): hidden = e4m3(8 * GELU(dequant(X8 W1_8^T) + b1)), then
+    // y2 = prob * (dequant(hidden8 W2_8^T) / 8 + b2).  Row scales come from the router kernel, channel scales from packing.
+    const float HS = 8.f;  // static hidden scale: GELU outputs of O(1) land in e4m3's normal range [2^-6, 448]
+    {
+      GemmArgs g8 = gd(c);
+      g8.A.p = w.hn, g8.A.ld = D, g8.A.kind = MDM_OP_FP8_ROW, g8.A.gather = w.perm;
+      g8.W.p = l.w1.hi, g8.W.ld = l.w1.ld, g8.W.kind = MDM_OP_FP8_ROW, g8.W.bs1 = (int64_t)F * l.w1.ld;
+      g8.a_scale = w.hn_scale, g8.w_scale = (const float*)l.w1.lo;
+      g8.goff = w.goff, g8.ngroups = 2 * E;
+      g8.M = (int)(4 * c.M), g8.N = F, g8.K = D;
+      g8.bias = l.b1, g8.bias_bs = F, g8.act = ACT_GELU;
+      g8.C8 = (uint8_t*)w.hid, g8.c8_scale = HS, g8.ldc = F;
+      MDM_TRY(gemm(g8, c.s));
+    }
+    {
+      GemmArgs g8 = gd(c);
+      g8.A.p = w.hid, g8.A.ld = F, g8.A.kind = MDM_OP_FP8_ROW;
+      g8.W.p = l.w2.hi, g8.W.ld = l.w2.ld, g8.W.kind = MDM_OP_FP8_ROW, g8.W.bs1 = (int64_t)D * l.w2.ld;
+      g8.a_scale_u = 1.f / HS, g8.w_scale = (const float*)l.w2.lo;
+      g8.goff = w.goff, g8.ngroups = 2 * E;
+      g8.M = (int)(4 * c.M), g8.N = D, g8.K = F;
+      g8.bias = l.b2, g8.bias_bs = D;
+      g8.rowscale = w.rowscale;
+      g8.C16 = (uint16_t*)w.y2, g8.ldc = D;
+      MDM_TRY(gemm(g8, c.s));
+    }
+    return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, true);
+  }
   if (h && g_bf16_variant != 21 && fused_mlp_supported(f)) {  // variant 21: two-GEMM chain, for A/B runs
     // throughput mode: both expert GEMMs in one kernel, hidden activations stay in LDS (switch_moe.py:19-25,104-109)
     const bool y16 = c.bf && g_bf16_variant != 25;  // expert outputs stored in 16 bits (what autocast does to a Linear); knob 25 / mixed mode: fp32
@@ -604,7 +638,7 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
   // computed once per caption batch, never per step: always the bf16x3 arithmetic (its weights are packed bf16 hi + lo in
   // every mode); `precision` only selects the 16-bit format of the folded K' / V' images
   c.m = m, c.s = (hipStream_t)stream, c.prec = 3, c.bf = false, c.mix = false, c.B = tc->B, c.N = tc->N;
-  c.h16 = (precision == MDM_PREC_F16 || precision == MDM_PREC_MIXED) ? MDM_H16_F16 : MDM_H16_BF16;
+  c.h16 = (precision == MDM_PREC_F16 || precision == MDM_PREC_MIXED || precision == MDM_PREC_FP8) ? MDM_H16_F16 : MDM_H16_BF16;
   c.w = carve(*m, tc->B, 2, tc->N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const int D = m->D, H = m->H, dh = D / H, N = tc->N, B = tc->B;

@@ -349,13 +349,15 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
       float logit[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) logit[e] = 0.f;
+      float amax = 0.f;  // fp8 rows: per-row scale from the largest |LN output|
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
         const int k = 4 * (l16 + 16 * c);
         const f32x4 w = *(const f32x4*)(p.ln_w[br] + k), b = *(const f32x4*)(p.ln_b[br] + k);
         const f32x4 h = {v[c][0] * rstd * w[0] + b[0], v[c][1] * rstd * w[1] + b[1], v[c][2] * rstd * w[2] + b[2],
                          v[c][3] * rstd * w[3] + b[3]};
-        if (ok) {
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(h[0]), fabsf(h[1])), fmaxf(fabsf(h[2]), fabsf(h[3]))));
+        if (ok && p.hn_bf16 != 3) {
           if (p.hn_bf16) {
             *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_h16(p.hn_bf16, h[0], h[1]), pack_h16(p.hn_bf16, h[2], h[3]));
           } else {
@@ -368,6 +370,20 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
             const f32x4 g = *(const f32x4*)(gw + (br * E + e) * D + k);
             logit[e] += h[0] * g[0] + h[1] * g[1] + h[2] * g[2] + h[3] * g[3];
           }
+      }
+      if (p.hn_bf16 == 3) {  // e4m3 rows, scale = amax / 448 (the LayerNorm output is recomputed: cheaper than keeping it)
+        amax = group_max<16>(amax);
+        const float scale = amax > 0.f ? amax * (1.f / 448.f) : 1.f, inv = 1.f / scale;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          const int k = 4 * (l16 + 16 * c);
+          const f32x4 w = *(const f32x4*)(p.ln_w[br] + k), b = *(const f32x4*)(p.ln_b[br] + k);
+          uint32_t q = 0;
+          q = __builtin_amdgcn_cvt_pk_fp8_f32((v[c][0] * rstd * w[0] + b[0]) * inv, (v[c][1] * rstd * w[1] + b[1]) * inv, q, false);
+          q = __builtin_amdgcn_cvt_pk_fp8_f32((v[c][2] * rstd * w[2] + b[2]) * inv, (v[c][3] * rstd * w[3] + b[3]) * inv, q, true);
+          if (ok) *(uint32_t*)((uint8_t*)p.hn + ((int64_t)br * M + row) * D + k) = q;
+        }
+        if (ok && l16 == 0) p.hn_scale[(int64_t)br * M + row] = scale;
       }
       // top-2 is decided on the LOGITS (softmax is monotone; ties -> lowest index), the softmax denominator is built
       // with one exp per lane (lane e owns expert e) instead of E exps in every lane

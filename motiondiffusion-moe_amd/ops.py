@@ -18,10 +18,24 @@ class PackedWeight:
     def __init__(self, w: torch.Tensor, with_lo: bool = True, fmt: Optional[str] = None):
         L.require_cuda(w)
         fmt = fmt or ("bf16x2" if with_lo else "bf16")
-        if fmt not in ("bf16x2", "bf16", "f16"):
+        if fmt not in ("bf16x2", "bf16", "f16", "f8"):
             raise ValueError(f"unknown packed weight format {fmt!r}")
         self.fmt = fmt
         with_lo = fmt == "bf16x2"
+        if fmt == "f8":  # e4m3 bytes (K padded to 128) in `hi`, per-row fp32 scales (amax / 448) in `lo`: csrc/gemm8.hip
+            w = w.detach().to(torch.float32)
+            self.lead = tuple(w.shape[:-2])
+            n, k = w.shape[-2], w.shape[-1]
+            w2 = w.reshape(-1, k).contiguous()
+            kp = (k + 127) // 128 * 128
+            self.N, self.K, self.Kp = n, k, kp
+            self.hi = torch.empty((w2.shape[0], kp), dtype=torch.uint8, device=w.device)
+            self.lo = torch.empty((w2.shape[0],), dtype=torch.float32, device=w.device)
+            with torch.cuda.device(w.device):
+                L.check(L.lib().mdm_pack_fp8(C.c_void_p(w2.data_ptr()), C.c_int64(k), C.c_int64(w2.shape[0]), C.c_int64(k),
+                                             C.c_void_p(self.hi.data_ptr()), C.c_int64(kp), C.c_void_p(self.lo.data_ptr()),
+                                             C.c_void_p(L.stream_ptr())), "mdm_pack_fp8")
+            return
         w = w.detach().to(torch.float32)
         lead = w.shape[:-2]
         n, k = w.shape[-2], w.shape[-1]
@@ -109,6 +123,41 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
         d.R2, d.ldr2 = r2.data_ptr(), r2.stride(0)
     run_gemm(d)
     return out.reshape(*x.shape[:-1], w.N)
+
+
+def quantize_rows_fp8(x: torch.Tensor):
+    """fp32 rows (M, K) -> (e4m3 bytes (M, Kp) uint8, scales (M,) fp32) with the library's own quantiser (amax / 448 per row,
+    K zero-padded to a multiple of 128): what the router kernel writes for the experts in the fp8 mode."""
+    L.require_cuda(x)
+    pw = PackedWeight(x, fmt="f8")
+    return pw.hi, pw.lo
+
+
+def gemm_fp8(a8: torch.Tensor, a_scale: Optional[torch.Tensor], w: PackedWeight, bias: Optional[torch.Tensor] = None, *,
+             act: int = L.ACT_NONE, a_scale_u: float = 1.0, rowscale=None, gather=None, goff=None, rows: Optional[int] = None,
+             out: Optional[torch.Tensor] = None, out8: Optional[torch.Tensor] = None, c8_scale: float = 1.0) -> torch.Tensor:
+    """C = act((A8 W8^T) * a_scale_u * a_scale[src row] * w_scale[n] + bias) * rowscale  (csrc/gemm8.hip).  ``goff`` selects
+    grouped mode (w / bias carry a leading group axis); ``out8`` receives e4m3(C * c8_scale)."""
+    assert w.fmt == "f8" and a8.dtype == torch.uint8 and a8.stride(-1) == 1
+    M = a8.shape[0] if rows is None else rows
+    d = gemm_desc(1)
+    d.A.p, d.A.ld, d.A.kind, d.A.gather = a8.data_ptr(), a8.stride(0), L.OP_FP8_ROW, L.ptr(gather)
+    d.W.p, d.W.ld, d.W.kind = w.hi.data_ptr(), w.Kp, L.OP_FP8_ROW
+    d.M, d.N, d.K = M, w.N, w.Kp
+    d.a_scale, d.w_scale, d.a_scale_u, d.c8_scale = L.ptr(a_scale), w.lo.data_ptr(), a_scale_u, c8_scale
+    if goff is not None:
+        d.goff, d.ngroups = goff.data_ptr(), goff.numel() - 1
+        d.W.bs1, d.bias_bs = w.N * w.Kp, w.N
+    d.bias, d.act, d.rowscale = L.ptr(bias), act, L.ptr(rowscale)
+    if out is None and out8 is None:
+        out = torch.empty((M, w.N), dtype=torch.float32, device=a8.device)
+    if out is not None:
+        d.C, d.ldc = out.data_ptr(), out.stride(0)
+    if out8 is not None:
+        d.C8, d.ldc = out8.data_ptr(), out8.stride(0)
+        assert out is None or out.stride(0) == out8.stride(0)
+    run_gemm(d)
+    return out if out is not None else out8
 
 
 def mlp_fragment_major(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype):

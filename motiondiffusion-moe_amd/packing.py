@@ -27,7 +27,7 @@ _MLP_LAYER = ("w1", "w2", "sd_f1", "sd_f2")  # the MFMA-bound GEMMs: expert MLPs
 
 def format_class(precision: int) -> str:
     """Packed models are shared between precisions that read the same planes."""
-    return {L.PREC_BF16: "bf16", L.PREC_X3: "bf16", L.PREC_F16: "f16", L.PREC_MIXED: "mixed"}[precision]
+    return {L.PREC_BF16: "bf16", L.PREC_X3: "bf16", L.PREC_F16: "f16", L.PREC_MIXED: "mixed", L.PREC_FP8: "f8"}[precision]
 
 
 def weight_format(name: str, precision: int, head_dim: int) -> str:
@@ -37,6 +37,8 @@ def weight_format(name: str, precision: int, head_dim: int) -> str:
         return "bf16x2"
     if leaf.endswith("feat") and head_dim != 128:  # no fused Performer core: the feature GEMM reads fp32 rows
         return "bf16x2"
+    if precision == L.PREC_FP8:
+        return "f8" if leaf in ("w1", "w2") else "f16"
     if precision == L.PREC_F16:
         return "f16"
     if precision == L.PREC_MIXED and leaf in _MLP_LAYER:
@@ -252,5 +254,6 @@ class PackedModel:
         l.sd_ln_w, l.sd_ln_b = V[k + "sd_ln_w"].data_ptr(), V[k + "sd_ln_b"].data_ptr()
 
     def nbytes(self) -> int:
-        n = sum(w.hi.numel() * 2 * (2 if w.lo is not None else 1) for w in self.W.values())
+        n = sum(w.hi.numel() * w.hi.element_size() + (w.lo.numel() * w.lo.element_size() if w.lo is not None else 0)
+                for w in self.W.values())
         return n + sum(v.numel() * 4 for v in self.V.values())

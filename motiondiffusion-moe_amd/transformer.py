@@ -300,9 +300,9 @@ class MotionTransformer(nn.Module):
         tc = L.TextCache()
         tc.lin_at, tc.sd_k, tc.sd_v, tc.B, tc.N = at.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, N
         fold = ()
-        if self.precision in (L.PREC_BF16, L.PREC_F16) and D == 512 and H * N <= 128:
+        if self.precision in (L.PREC_BF16, L.PREC_F16, L.PREC_FP8) and D == 512 and H * N <= 128:
             # throughput modes: query / output projections of the text cross-attention folded into the text side
-            h16 = torch.float16 if self.precision == L.PREC_F16 else torch.bfloat16
+            h16 = torch.bfloat16 if self.precision == L.PREC_BF16 else torch.float16
             fold = (torch.zeros((L2, B, 128, D), dtype=h16, device=dev),
                     torch.zeros((L2, B, 128), dtype=torch.float32, device=dev),
                     torch.zeros((L2, B, D, 128), dtype=h16, device=dev))

@@ -279,3 +279,52 @@ def test_bf16_256_tile_grouped_gather(force_256):
         ref[r] = torch.nn.functional.gelu(x.cpu().double()[gather[r].long()] @ wb[e].T + b[e].cpu().double())
     ref = ref * rs.cpu().double()[:, None]
     assert rel_inf(out.cpu(), ref.float()) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,grouped", [(12544, 512, 512, False), (300, 263, 1024, False), (515, 1024, 512, True)])
+def test_x3_dma_kernel_against_the_register_staged_one(M, N, K, grouped):
+    """fp32-grade Linears run on the LDS-DMA staged bf16x3 kernel (csrc/gemm3.hip); knob 36 selects the register-staged
+    kernel (csrc/gemm.hip).  Same split operands, different accumulation order: both within 2e-5 of fp64, and different bits."""
+    L, ops = _mods()
+    G = 3 if grouped else 1
+    x, b = _rand(M, K, seed=1), _rand(G, N, seed=3)
+    w = _rand(G, N, K, seed=2) * K ** -0.5
+    pw = ops.PackedWeight(w if grouped else w[0])
+    sizes = [200, 0, 315] if grouped else [M]
+    goff = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    gather = torch.randint(0, M, (M,), generator=g, dtype=torch.int32).cuda() if grouped else None
+    rs = _rand(M, seed=6).abs()
+    r1 = _rand(M, N, seed=7)
+
+    def run():
+        d = ops.gemm_desc(3)
+        d.A = ops.f32_operand(x, K)
+        d.A.gather = L.ptr(gather)
+        d.W = pw.operand()
+        d.M, d.N, d.K = M, N, K
+        out = torch.zeros(M, N, device="cuda")
+        d.C, d.ldc = out.data_ptr(), N
+        d.bias, d.act, d.rowscale = b.data_ptr(), L.ACT_GELU, rs.data_ptr()
+        d.R1, d.ldr1, d.r1_scale = r1.data_ptr(), N, 0.5
+        if grouped:
+            d.goff, d.ngroups, d.W.bs1, d.bias_bs = goff.data_ptr(), G, N * pw.Kp, N
+        ops.run_gemm(d)
+        return out
+
+    new = run()
+    L.lib().mdm_set_gemm_variant(36)
+    try:
+        old = run()
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    xs = x[gather.long()] if grouped else x
+    ref = torch.empty(M, N, dtype=torch.float64, device="cuda")
+    o = 0
+    for e, n in enumerate(sizes):
+        ref[o:o + n] = torch.nn.functional.gelu(xs[o:o + n].double() @ w[e].double().T + b[e].double())
+        o += n
+    ref = ref * rs.double()[:, None] + 0.5 * r1.double()
+    e_new, e_old = rel_inf(new.cpu(), ref.float().cpu()), rel_inf(old.cpu(), ref.float().cpu())
+    print(f"x3 {M}x{N}x{K} grouped={grouped}: LDS-DMA kernel {e_new:.2e}, register-staged kernel {e_old:.2e}")
+    assert e_new < 2e-5 and e_old < 2e-5
