@@ -110,8 +110,10 @@ __global__ __launch_bounds__(NT3, 2) void gemm_x3_kernel(const GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
-    const int younger = min(NSTAGE - 2, nk - 1 - kt);
-    if (younger >= 1) {
+    const int younger = min(NSTAGE - 2, nk - 1 - kt);  // stages issued after this one that may stay in flight
+    if (younger >= 2) {
+      wait_vm3<2 * PIECES>();
+    } else if (younger == 1) {
       wait_vm3<PIECES>();
     } else {
       wait_vm3<0>();
@@ -243,6 +245,8 @@ int launch3(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+extern int g_bf16_variant;
+
 bool gemm_x3_dma_eligible(const GemmArgs& a) {
   return a.precision == 3 && a.A.kind == OP_F32_ROW && a.W.kind == OP_BF16_ROW && a.W.p_lo && a.batch == 1 && a.A.rpg == 0 &&
          a.K >= 32 && (a.K % 32) == 0 && (a.A.ld % 4) == 0 && (a.W.ld % 8) == 0 && (a.W.bs1 % 8) == 0 &&
@@ -255,6 +259,9 @@ int gemm_x3_dma(const GemmArgs& a, hipStream_t stream) {
   if (!a.C && !a.C16) return MDM_ERR_ARG;
   const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + BN3 - 1) / BN3);
   const bool small = !a.goff && (tiles128 <= 256 || a.M <= 64);
+  if (g_bf16_variant == 37) return launch3<128, 3>(a, stream);  // A/B knobs: ring depth at the 128-row tile
+  if (g_bf16_variant == 38) return launch3<128, 4>(a, stream);
+  if (g_bf16_variant == 39) return launch3<64, 3>(a, stream);
   return small ? launch3<64, 3>(a, stream) : launch3<128, 2>(a, stream);
 }
 
