@@ -299,6 +299,10 @@ int mdm_ddim_step(const float* x, const float* eps, const float* noise, int64_t 
 enum { MDM_NOISE_STREAM_XT = 0x7fffffff };
 int mdm_noise_normal(float* out, int64_t per_sample, int32_t nsamples, int64_t sample0, uint64_t seed,
                      const int32_t* stream_dev, int32_t stream_imm, void* stream);
+/* the same with one explicit global sample index per row (device int64 [nsamples]): length-bucketed batches whose rows are
+ * not consecutive samples (trainer.generate_bucketed) */
+int mdm_noise_normal_ids(float* out, int64_t per_sample, int32_t nsamples, const int64_t* sample_ids, uint64_t seed,
+                         const int32_t* stream_dev, int32_t stream_imm, void* stream);
 
 /* Text projection head of the reference's EnhancedTextEncoder (text_encoder.py:13-18,31-43), applied to the
  * last_hidden_state of any text encoder (the DeBERTa weights themselves are third-party and stay outside this library):

@@ -66,8 +66,8 @@ int text_assemble(const float* pp, const float* ph, int B, int N0, int P, int Dt
 int motion_post(const float* x, const int* len, const float* mean, const float* sd, int B, int T, int feats, int J,
                 int radius, const double* wts, float* raw, float* out, hipStream_t s);
 // noise.hip: Philox4x32-10 + Box-Muller, keyed on (seed, global sample, stream, element)
-int philox_normal(float* out, int64_t per_sample, int nsamples, int64_t sample0, uint64_t seed, const int* stream_dev,
-                  int stream_imm, hipStream_t s);
+int philox_normal(float* out, int64_t per_sample, int nsamples, int64_t sample0, const int64_t* sample_ids, uint64_t seed,
+                  const int* stream_dev, int stream_imm, hipStream_t s);
 int iota_i64(int64_t* dst, int64_t n, int64_t start, hipStream_t s);
 int xattn_gate(const float* gate, const float* ag, int D, float* out, hipStream_t s);
 int halve_lengths(const int* len, int B, int* out, hipStream_t s);

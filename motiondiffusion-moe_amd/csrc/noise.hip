@@ -31,13 +31,14 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 __device__ __forceinline__ float u01(uint32_t b) { return ((float)(b >> 8) + 1.0f) * (1.0f / 16777216.0f); }
 
 __global__ void philox_normal_kernel(float* __restrict__ out, int64_t per_sample, int nsamples, int64_t sample0,
-                                     uint64_t seed, const int* __restrict__ stream_dev, int stream_imm) {
+                                     const int64_t* __restrict__ sample_ids, uint64_t seed,
+                                     const int* __restrict__ stream_dev, int stream_imm) {
   const uint32_t stream = (uint32_t)(stream_dev ? *stream_dev : stream_imm);
   const int64_t quads = (per_sample + 3) >> 2;  // 4 normals per Philox call
   const int64_t total = quads * nsamples;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t s = i / quads, qd = i - s * quads;
-    const uint64_t gs = (uint64_t)(sample0 + s);
+    const uint64_t gs = sample_ids ? (uint64_t)sample_ids[s] : (uint64_t)(sample0 + s);
     uint32_t c[4] = {(uint32_t)qd, (uint32_t)gs, (uint32_t)(gs >> 32), stream};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     float z[4];
@@ -61,14 +62,14 @@ __global__ void philox_normal_kernel(float* __restrict__ out, int64_t per_sample
 
 }  // namespace
 
-int philox_normal(float* out, int64_t per_sample, int nsamples, int64_t sample0, uint64_t seed, const int* stream_dev,
-                  int stream_imm, hipStream_t s) {
+int philox_normal(float* out, int64_t per_sample, int nsamples, int64_t sample0, const int64_t* sample_ids, uint64_t seed,
+                  const int* stream_dev, int stream_imm, hipStream_t s) {
   if (per_sample <= 0 || nsamples <= 0) return MDM_OK;
   if (!out || sample0 < 0) return MDM_ERR_ARG;
   const int64_t total = ((per_sample + 3) >> 2) * nsamples;
   int64_t blocks = (total + 255) / 256;
   hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, out, per_sample,
-                     nsamples, sample0, seed, stream_dev, stream_imm);
+                     nsamples, sample0, sample_ids, seed, stream_dev, stream_imm);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
@@ -77,5 +78,12 @@ int philox_normal(float* out, int64_t per_sample, int nsamples, int64_t sample0,
 
 extern "C" int mdm_noise_normal(float* out, int64_t per_sample, int32_t nsamples, int64_t sample0, uint64_t seed,
                                 const int32_t* stream_dev, int32_t stream_imm, void* stream) {
-  return mdm::philox_normal(out, per_sample, nsamples, sample0, seed, stream_dev, stream_imm, (hipStream_t)stream);
+  return mdm::philox_normal(out, per_sample, nsamples, sample0, nullptr, seed, stream_dev, stream_imm, (hipStream_t)stream);
+}
+
+// the same with an explicit GLOBAL sample index per row (device int64 [nsamples]): rows of a length-bucketed batch
+extern "C" int mdm_noise_normal_ids(float* out, int64_t per_sample, int32_t nsamples, const int64_t* sample_ids, uint64_t seed,
+                                    const int32_t* stream_dev, int32_t stream_imm, void* stream) {
+  if (!sample_ids) return MDM_ERR_ARG;
+  return mdm::philox_normal(out, per_sample, nsamples, 0, sample_ids, seed, stream_dev, stream_imm, (hipStream_t)stream);
 }

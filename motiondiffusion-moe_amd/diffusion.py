@@ -397,10 +397,7 @@ class _StepRunner:
         lib, s = L.lib(), C.c_void_p(L.stream_ptr())
         B, n = self.B, self.n
         if use_noise and self.philox is not None:  # step noise = f(seed, global sample, t, element); t read on the device
-            seed, first = self.philox
-            L.check(lib.mdm_noise_normal(C.c_void_p(self.noise.data_ptr()), C.c_int64(self.T * self.Fe), C.c_int32(B),
-                                         C.c_int64(first), C.c_uint64(seed), C.c_void_p(self.t_dev.data_ptr()), C.c_int32(0), s),
-                    "mdm_noise_normal")
+            self._philox_fill(self.noise, C.c_void_p(self.t_dev.data_ptr()), 0, s)
         x = self.xx[:B]
         if self.R == 2 * B:
             self.xx[B:].copy_(x)
@@ -451,14 +448,36 @@ class _StepRunner:
             self.model.moe_buffers()[k].copy_(v)
         torch.cuda.current_stream().synchronize()
 
-    def draw_xT(self, seed: int, first: int = 0):
-        """x_T for rows [first, first + B) of a global batch: the counter-based generator's MDM_NOISE_STREAM_XT stream."""
+    def _philox_fill(self, out, stream_dev, stream_imm, s):
+        """out[row] = noise(seed, global sample of that row, stream): rows are consecutive samples (first + row) or carry
+        explicit global indices (self.philox = (seed, int64 device tensor))."""
+        seed, first = self.philox
+        lib, per = L.lib(), C.c_int64(self.T * self.Fe)
+        if torch.is_tensor(first):
+            L.check(lib.mdm_noise_normal_ids(C.c_void_p(out.data_ptr()), per, C.c_int32(self.B), C.c_void_p(first.data_ptr()),
+                                             C.c_uint64(seed), stream_dev, C.c_int32(stream_imm), s), "mdm_noise_normal_ids")
+        else:
+            L.check(lib.mdm_noise_normal(C.c_void_p(out.data_ptr()), per, C.c_int32(self.B), C.c_int64(first),
+                                         C.c_uint64(seed), stream_dev, C.c_int32(stream_imm), s), "mdm_noise_normal")
+
+    def draw_xT(self, seed: int, first=0):
+        """x_T for rows [first, first + B) of a global batch (or the rows whose global indices `first` lists): the
+        counter-based generator's MDM_NOISE_STREAM_XT stream."""
         out = torch.empty((self.B, self.T, self.Fe), dtype=torch.float32, device=self.dev)
+        keep = self.philox
+        self.philox = (int(seed) & 0xFFFFFFFFFFFFFFFF, self._ids(first))
         with torch.cuda.device(self.dev):
-            L.check(L.lib().mdm_noise_normal(C.c_void_p(out.data_ptr()), C.c_int64(self.T * self.Fe), C.c_int32(self.B),
-                                             C.c_int64(first), C.c_uint64(seed), C.c_void_p(0), C.c_int32(L.NOISE_STREAM_XT),
-                                             C.c_void_p(L.stream_ptr())), "mdm_noise_normal")
+            self._philox_fill(out, C.c_void_p(0), L.NOISE_STREAM_XT, C.c_void_p(L.stream_ptr()))
+        self.philox = keep
         return out
+
+    def _ids(self, sample_offset):
+        if torch.is_tensor(sample_offset) or isinstance(sample_offset, (list, tuple)):
+            ids = torch.as_tensor(sample_offset).to(device=self.dev, dtype=torch.int64).contiguous()
+            if ids.numel() != self.B:
+                raise ValueError("sample_offset as a sequence must list one global sample index per row")
+            return ids
+        return int(sample_offset)
 
     def run(self, noise, step_noise, progress, callback, seed: Optional[int] = None, sample_offset: int = 0):
         """``seed``: draw x_T (when ``noise`` is None) and every step's noise (when ``step_noise`` is None) from the
@@ -466,7 +485,7 @@ class _StepRunner:
         the same noise whatever the batch split.  Without a seed the torch generator is used, like the reference."""
         d, B = self.d, self.B
         if seed is not None and step_noise is None:
-            self.philox = (int(seed) & 0xFFFFFFFFFFFFFFFF, int(sample_offset))
+            self.philox = (int(seed) & 0xFFFFFFFFFFFFFFFF, self._ids(sample_offset))
         self._prepare()
         if self.use_graph:
             g = torch.cuda.CUDAGraph()

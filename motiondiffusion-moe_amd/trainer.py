@@ -74,7 +74,9 @@ class DDPMTrainer(object):
         """Evaluation-scale variant of ``generate``: same inputs and the same kind of result (a
         list of per-sample ``(T_batch, dim_pose)`` tensors in the caller's order, valid up to each sample's length),
         but batches hold samples of similar length (less padded work) and, under ``torch.distributed``, are dealt over
-        the ranks with one all_gather at the end.  ``seed`` makes every batch's noise a function of (seed, batch id)."""
+        the ranks with one all_gather at the end.  With ``seed`` every sample's noise is a function of (seed, its index in
+        ``caption``) only -- the same as ``generate(..., seed=)`` -- so on each sample's valid frames the two give identical
+        results whatever the bucketing (tests/test_sampler_gpu.py)."""
         from . import dist as D
         m = self._model()
         self.eval_mode()
@@ -88,7 +90,7 @@ class DDPMTrainer(object):
             return self.diffusion.p_sample_loop_with_cfg(
                 m, (len(cap), T, dim_pose), clip_denoised=False, progress=progress,
                 model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out, "length": ln, "text": cap}, cfg_scale=self.cfg_scale,
-                seed=None if seed is None else (int(seed) * 1000003 + k))  # bucket k: its own stream of the generator
+                seed=seed, sample_offset=idx)  # noise keyed on each row's index in the CALLER's list: == generate(seed=)
 
         return D.run_plan(plan, run_bucket, len(caption), m.num_frames, dim_pose, self.device, group)
 

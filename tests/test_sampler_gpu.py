@@ -201,6 +201,33 @@ def test_bucketed_generation_and_joints():
         assert rel_inf(j.cpu(), torch.from_numpy(ref)) < 5e-6, i
 
 
+def test_bucketed_generation_equals_serial_generation_on_valid_frames():
+    """generate_bucketed (length-sorted batches) against the reference-shaped serial generate on the
+    SAME seed: noise is keyed on (seed, index in the caller's list, timestep, element), frames past a sample's length never
+    reach its valid frames (masked keys, per-token ops), so every sample's valid frames must agree although the two
+    drivers batch and pad differently."""
+    g, meta, m, diff, noises, kw = _setup()
+    Tr = pkg("trainer")
+    synth = pkg("synth")
+    Dt = meta["text_latent_dim"]
+
+    def enc(text, device):  # a different embedding per caption, so a mixed-up order would show
+        xo = torch.stack([synth.uniform_pm1((6, Dt), "cap." + t, 1) * (3.0 ** 0.5) for t in text])
+        return xo.mean(1).to(device), xo.to(device)
+
+    m.text_encoder_fn = enc
+    args = types.SimpleNamespace(device=torch.device("cuda"), diffusion_steps=25, is_train=False, cfg_scale=2.5)
+    tr = Tr.DDPMTrainer(args, m)
+    caps, lens = ["a", "b", "c", "d", "e"], torch.tensor([8, 16, 12, 16, 4])
+    serial = tr.generate(caps, lens, 263, batch_size=2, seed=3)
+    bucket = tr.generate_bucketed(caps, lens, 263, batch_size=2, unit_length=4, seed=3)
+    other = tr.generate(caps, lens, 263, batch_size=3, seed=3)
+    for i, n in enumerate(lens.tolist()):
+        a, b, c = serial[i][:n].cpu(), bucket[i][:n].cpu(), other[i][:n].cpu()
+        assert rel_inf(b, a) < 1e-4 and rel_inf(c, a) < 1e-4, (i, rel_inf(b, a), rel_inf(c, a))
+    assert not torch.allclose(tr.generate(caps, lens, 263, batch_size=2, seed=4)[1].cpu(), serial[1].cpu())
+
+
 def test_training_losses_values_match_oracle():
     """Forward-only evaluation of the reference's training objective (gaussian_diffusion.py:923-985): the MSE term against
     the oracle's forward on the same x_t, and the load-balancing term against the oracle's counters."""
