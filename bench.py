@@ -394,8 +394,8 @@ def main():
         live = probe_dominant_kernel(r, m) if not r.chunks else None  # single-stream steps only
         modes = None if (a.no_modes or a.sampler != "cfg" or a.config != "small") else mode_table(a, m, inputs, host, diff, kw, dev, a.precision, ms)
         traffic = None  # HBM-side bytes per step from the committed PMC passes (same workload only)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and (a.config, B, T, a.precision) == ("small", 32, 196, 1) and False:  # r01 passes: stale
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(pmc) and (a.config, B, T, a.precision, a.sampler) == ("small", 32, 196, 2, "cfg"):
             traffic = json.load(open(pmc))["total_bytes_per_step"]
         cfgname = {"small": "configs[1]", "big": "configs[2]" if a.sampler == "cfg" else "configs[3]", "big16": "configs[4]"}[a.config]
         stepdesc = (f"{a.schedule}-step DDPM with CFG {a.cfg_scale} (cond+uncond batched as {2 * B} rows)" if a.sampler == "cfg"
@@ -413,7 +413,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK[a.precision] / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.precision], 4), "traffic": traffic,
                          "traffic_note": "fabric bytes per step from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, "
-                                         "profiles/r01_pmc_traffic.json" if traffic else None,
+                                         "profiles/r02_pmc_traffic.json" if traffic else None,
                          "what": "whole step: algorithmic FLOP of 2 forwards / wall time per step",
                          "whole_step": {"achieved": round(achieved / 1e12, 2), "frac": round(achieved / PEAK[a.precision], 4),
                                         "traffic": traffic},
@@ -436,7 +436,7 @@ def main():
             rf.update({"achieved": round(live[1] / live[0] / 1e12, 2), "frac": round(live[1] / live[0] / PEAK[a.precision], 4),
                        "traffic": pmc_k,
                        "traffic_note": "fabric bytes per launch of this kernel (mean over its launches in a step), rocprofv3 "
-                                       "--pmc FETCH_SIZE(x2) / WRITE_SIZE passes, profiles/r01_pmc_traffic.json" if pmc_k else None,
+                                       "--pmc FETCH_SIZE(x2) / WRITE_SIZE passes, profiles/r02_pmc_traffic.json" if pmc_k else None,
                        "what": "dominant kernel fused_mlp_kernel (expert W1-GELU-W2, csrc/mlp.hip): mean algorithmic FLOP per "
                                "launch (4 * routed rows * D * F) / mean launch duration over the launches of real sampling "
                                "steps; the whole step is under whole_step",
