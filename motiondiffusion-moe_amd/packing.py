@@ -35,7 +35,7 @@ def weight_format(name: str, precision: int, head_dim: int) -> str:
     leaf = name.split(".", 1)[1] if name.startswith("L") and "." in name else name
     if name in _ALWAYS_X3 or leaf in _ALWAYS_X3_LAYER:
         return "bf16x2"
-    if leaf.endswith("feat") and head_dim != 128:  # no fused Performer core: the feature GEMM reads fp32 rows
+    if leaf.endswith("feat") and head_dim not in (128, 256):  # no fused Performer core: the feature GEMM reads fp32 rows
         return "bf16x2"
     if precision == L.PREC_FP8:
         return "f8" if leaf in ("w1", "w2") else "f16"

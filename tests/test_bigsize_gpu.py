@@ -166,3 +166,51 @@ def test_configs3_ddim_steps_of_a_100_step_schedule():
     a = diff.ddim_sample_loop(m, (B, T, 263), clip_denoised=False, model_kwargs=kw, eta=0.0, seed=5)
     b = diff.ddim_sample_loop(m, (B, T, 263), clip_denoised=False, model_kwargs=kw, eta=0.0, seed=5)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision,tol", [(2, 6e-4), (1, 4e-3)])
+@pytest.mark.parametrize("S", [40, 98, 196])
+def test_big_width_performer_core_fused_kernel(S, precision, tol):
+    """head_dim 256 (big model): mdm_performer_attn_forward runs the fused core of csrc/perf_attn2.hip (feature / value halves,
+    KV^T through an L2-resident scratch) in the 16-bit modes -- against the oracle's PerformerSelfAttention, both attention
+    slots, ragged lengths, S not a multiple of the tile sizes; knob 23 selects the GEMM-composed chain on the same inputs."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from conftest import build_module, load_golden
+    g, meta = load_golden("fwd_big_dims")
+    m, (sd, eph, proj, mcfg) = build_module(meta, precision=precision)
+    L, synth = pkg("_lib"), pkg("synth")
+    lib, pm = L.lib(), m.pack()
+    D, H, B = 1024, 4, 3
+    h = synth.uniform_pm1((B, S, D), "blk.h", S) * 1.5
+    emb = synth.uniform_pm1((B, D), "blk.emb", S)
+    length = torch.tensor([S, max(1, S - 13), max(1, S // 2)])
+    pre = "decoder_blocks_low.0.module"
+    mask = R.src_mask(S, length)
+    ws = m._workspace(B, S, 1)
+    hd, ld = h.cuda().contiguous(), length.to(torch.int32).cuda()
+    for which, slot in ((0, "local"), (1, "global")):
+        sp = f"{pre}.dual_self_attn.{slot}_attn.style_block"
+        w, b = eph[f"low.0.{slot}_style"]
+        sc = F.linear(F.silu(F.linear(emb, w, b)), sd[sp + ".emb_layers.1.weight"], sd[sp + ".emb_layers.1.bias"]).cuda().contiguous()
+
+        def run():
+            out = torch.empty_like(hd)
+            L.check(lib.mdm_performer_attn_forward(C.byref(pm.model), C.c_int32(0), C.c_int32(which), C.c_void_p(hd.data_ptr()),
+                                                   C.c_void_p(sc.data_ptr()), C.c_void_p(ld.data_ptr()), C.c_int32(B), C.c_int32(S),
+                                                   C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()),
+                                                   C.c_int32(precision), C.c_void_p(L.stream_ptr())))
+            return out.cpu()
+
+        fused = run()
+        lib.mdm_set_gemm_variant(23)
+        try:
+            chain = run()
+        finally:
+            lib.mdm_set_gemm_variant(0)
+        with torch.no_grad():
+            ref = R.performer_self_attention(h, emb, mask, sd, f"{pre}.dual_self_attn.{slot}_attn", H, eph[f"low.0.{slot}_style"],
+                                             proj[f"low.0.{slot}"])
+        e_f, e_c = rel_inf(fused, ref), rel_inf(chain, ref)
+        print(f"big performer {slot} S={S} precision {precision}: fused {e_f:.2e}, GEMM-composed chain {e_c:.2e}")
+        assert e_f < tol and not torch.equal(fused, chain)
