@@ -43,9 +43,10 @@ int head_softmax(float* q, int64_t units, int dh, hipStream_t s);
 bool perf_attn_supported(int dh, int S);
 int perf_attn(const void* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s);
-// perf_attn2.hip: the same core at head_dim 256 (big model), blocked over feature / value halves; scratch: 139 KB per (b, h)
+// perf_attn2.hip: the same core at head_dim 256 (big model) in two launches (feature maps; KV state + num + LN); scratch:
+// qphi | kphi^T | den, perf_attn256_scratch_bytes()
 bool perf_attn256_supported(int dh, int S);
-int64_t perf_attn256_scratch_bytes(int B, int H);
+int64_t perf_attn256_scratch_bytes(int B, int H, int S);
 int perf_attn256(const void* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len,
                  int B, int S, int H, uint16_t* out, void* scratch, hipStream_t s);
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);

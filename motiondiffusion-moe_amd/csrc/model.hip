@@ -196,7 +196,7 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
   const int D = m.D, H = m.H, dh = D / H, mf = dh;  // m = min(dh, 256) = dh for dh <= 256
   const Work& w = c.w;
   const bool fused256 = c.bf && g_bf16_variant != 23 && perf_attn256_supported(dh, c.S) &&
-                        perf_attn256_scratch_bytes(c.B, H) <= (int64_t)c.B * H * dh * dh * (int64_t)sizeof(float);
+                        perf_attn256_scratch_bytes(c.B, H, c.S) <= c.M * 2 * D * (int64_t)sizeof(float);
   const bool fused = fused256 || (c.bf && perf_attn_supported(dh, c.S));
   // q|k|v = 0.1 * (xn W^T + b)                                   (:145-157); bf16 when the fused attention core reads it
   {
@@ -205,8 +205,9 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, fused ? nullptr : w.qkv, fused ? (uint16_t*)w.qkv : nullptr, o));
   }
   if (fused256) {
-    // the same at head_dim 256 (big model), blocked over feature / value halves; KV^T halves pass through w.kvt (L2)
-    MDM_TRY(perf_attn256(w.qkv, c.h16, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, (uint16_t*)w.t4, w.kvt, c.s));
+    // the same at head_dim 256 (big model) in two launches: feature maps (P^T resident), then KV state + num + LN per
+    // (batch, head); qphi / kphi^T / den pass through w.phi (L2 / MALL resident)
+    MDM_TRY(perf_attn256(w.qkv, c.h16, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, (uint16_t*)w.t4, w.phi, c.s));
   } else if (fused) {
     // throughput mode: LN/L2 -> feature maps -> KV state -> num/den -> LN in ONE kernel per (batch, head)  (:44-90)
     MDM_TRY(perf_attn(w.qkv, c.h16, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, (uint16_t*)w.t4, c.s));
