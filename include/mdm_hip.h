@@ -86,6 +86,9 @@ typedef struct MdmGemmDesc {
   float a_scale_u;      /* uniform activation scale (1 by default) */
   uint8_t* C8;          /* optional fp8 output e4m3(v * c8_scale), same ldc */
   float c8_scale;
+  /* weight-gradient mode (both operands MDM_OP_F32_KSTRIDE, no goff): batch z reduces over the K range
+   * [kgoff[z], kgoff[z+1]) -- the routed rows of expert group z -- instead of [0, K); an empty range writes epilogue(0) */
+  const int32_t* kgoff;
 } MdmGemmDesc;
 
 int mdm_gemm(const MdmGemmDesc* desc, void* stream);
@@ -324,6 +327,49 @@ int mdm_text_head_forward(const float* hidden, const float* prompts, const float
 int mdm_motion_postprocess(const float* motion, const int32_t* length, const float* mean, const float* std, int32_t B,
                            int32_t T, int32_t feats, int32_t joints, int32_t radius, const double* weights,
                            float* scratch, float* joints_out, void* stream);
+
+/* ---- training step of the MoE feed-forward block --------------------------------------------
+ * MoEMultiBranchFFN.forward (multi_branch.py:52-61) with both SwitchMoELayers (switch_moe.py:44-111) and the StylizationBlock
+ * (stylization.py:20-31) in training mode, and its backward: what loss.backward() does for this block inside
+ * DDPMTrainer.update (ddpm_trainer.py:228-244).  fp32 master parameters in the state_dict layouts, the two branches stacked on
+ * a leading dimension; the same struct holds the gradients (same shapes, OVERWRITTEN by the backward).  Dropout is taken at
+ * p = 0.  The GEMMs are the bf16x3 (fp32-grade) kernel; gradients match fp32 autograd to ~1e-4 relative. */
+typedef struct MdmMoeTensors {
+  float* ln_w;      /* [2][D]        branches.{b}.layernorm.weight */
+  float* ln_b;      /* [2][D] */
+  float* gate_w;    /* [2][E][D]     branches.{b}.moe.gate.weight */
+  float* gate_b;    /* [2][E] */
+  float* w1;        /* [2][E][F][D]  branches.{b}.moe.experts.{e}.0.weight */
+  float* b1;        /* [2][E][F] */
+  float* w2;        /* [2][E][D][F]  branches.{b}.moe.experts.{e}.2.weight */
+  float* b2;        /* [2][E][D] */
+  float* st_emb_w;  /* [2D][Te]      proj_out.emb_layers.1.weight */
+  float* st_emb_b;  /* [2D] */
+  float* st_norm_w; /* [D]           proj_out.norm */
+  float* st_norm_b;
+  float* st_out_w;  /* [D][D]        proj_out.out_layers.2.weight */
+  float* st_out_b;  /* [D] */
+} MdmMoeTensors;
+
+int64_t mdm_moe_train_workspace_bytes(int32_t B, int32_t S, int32_t D, int32_t F, int32_t E, int32_t Te);
+/* out = x + proj_out(mean_b moe_b(LN_b(x)), emb): x [B*S, D], emb [B, De]; when De != Te the captured per-call projection
+ * eph_w [Te, De], eph_b [Te] of stylization.py:22-24 is applied first (not trained).  lb_loss (optional, device [2]):
+ * get_load_balancing_loss (switch_moe.py:113-145) of the two layers from this forward's counters.  route_out (optional):
+ * the top-2 decisions, int32 [2][B*S][2].  Activations needed by the backward stay in ws. */
+int mdm_moe_ffn_train_forward(const MdmMoeTensors* params, int32_t D, int32_t F, int32_t E, int32_t Te, int32_t De,
+                              const float* eph_w, const float* eph_b, const float* x, const float* emb, int32_t B, int32_t S,
+                              float* out, float* lb_loss, int32_t* route_out, void* ws, int64_t ws_bytes, void* stream);
+/* given dout = dL/dout [B*S, D] and the workspace of the matching forward: dx [B*S, D], demb [B, De] (optional) and every
+ * parameter gradient in `grads`. */
+int mdm_moe_ffn_train_backward(const MdmMoeTensors* params, int32_t D, int32_t F, int32_t E, int32_t Te, int32_t De,
+                               const float* eph_w, const float* x, const float* emb, int32_t B, int32_t S, const float* dout,
+                               float* dx, float* demb, const MdmMoeTensors* grads, void* ws, int64_t ws_bytes, void* stream);
+/* optimizer plumbing of ddpm_trainer.py:228-244 on flat fp32 buffers: squared gradient norm (device scalar, for
+ * clip_grad_norm_) and one Adam step with the clip factor min(1, max_norm / (sqrt(*sumsq) + 1e-6)) folded in (sumsq NULL or
+ * max_norm <= 0: no clip). */
+int mdm_sumsq(const float* x, int64_t n, float* out, void* stream);
+int mdm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  int32_t step, const float* sumsq, float max_norm, void* stream);
 
 /* small helpers used by the host module */
 int mdm_xattn_gate(const float* gate, const float* adaptive_gate, int32_t D, float* out, void* stream);

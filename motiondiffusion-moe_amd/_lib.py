@@ -40,7 +40,14 @@ class GemmDesc(C.Structure):
                 ("R2", C.c_void_p), ("ldr2", C.c_int64), ("feat_len", C.c_void_p), ("feat_S", C.c_int32),
                 ("feat_rpt", C.c_int32), ("feat_kslot", C.c_int32), ("precision", C.c_int32), ("h16", C.c_int32),
                 ("a_scale", C.c_void_p), ("w_scale", C.c_void_p), ("a_scale_u", C.c_float), ("C8", C.c_void_p),
-                ("c8_scale", C.c_float)]
+                ("c8_scale", C.c_float), ("kgoff", C.c_void_p)]
+
+
+class MoeTensors(C.Structure):
+    """MdmMoeTensors: parameters (or gradients) of one MoE feed-forward block, branches stacked (include/mdm_hip.h)."""
+    NAMES = ("ln_w", "ln_b", "gate_w", "gate_b", "w1", "b1", "w2", "b2", "st_emb_w", "st_emb_b", "st_norm_w", "st_norm_b",
+             "st_out_w", "st_out_b")
+    _fields_ = [(n, C.c_void_p) for n in NAMES]
 
 
 class MlpDesc(C.Structure):
@@ -123,7 +130,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mdm_version.restype = C.c_char_p
         for name in EXPORTS:
-            if name in ("mdm_workspace_bytes", "mdm_text_head_workspace_bytes"):
+            if name in ("mdm_workspace_bytes", "mdm_text_head_workspace_bytes", "mdm_moe_train_workspace_bytes"):
                 getattr(L, name).restype = C.c_int64
             elif name != "mdm_version":
                 getattr(L, name).restype = C.c_int
@@ -135,7 +142,8 @@ def lib():
 EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_pack_bf16", "mdm_pack_f16", "mdm_pack_fp8", "mdm_workspace_bytes", "mdm_text_cache_build",
            "mdm_denoiser_forward", "mdm_stem_cache_build", "mdm_block_forward", "mdm_moe_ffn_forward", "mdm_dual_self_attn_forward", "mdm_linear_xattn_forward",
            "mdm_softmax_xattn_ffn_forward", "mdm_performer_attn_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
-           "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_noise_normal", "mdm_noise_normal_ids", "mdm_text_head_workspace_bytes", "mdm_text_head_forward", "mdm_motion_postprocess", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant", "mdm_debug_stamps", "mdm_probe_enable", "mdm_probe_read", "mdm_route_dump"]
+           "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_noise_normal", "mdm_noise_normal_ids", "mdm_text_head_workspace_bytes", "mdm_text_head_forward", "mdm_motion_postprocess", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant", "mdm_debug_stamps", "mdm_probe_enable", "mdm_probe_read", "mdm_route_dump",
+           "mdm_moe_train_workspace_bytes", "mdm_moe_ffn_train_forward", "mdm_moe_ffn_train_backward", "mdm_sumsq", "mdm_adam_step"]
 
 
 def check(status: int, what: str = "mdm call"):

@@ -207,8 +207,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   }
   const int z = blockIdx.z;
   const int z1 = z / g.nb2, z2 = z % g.nb2;
-  const int64_t offA = (int64_t)z1 * g.A.bs1 + (int64_t)z2 * g.A.bs2;
-  const int64_t offW = g.goff ? (int64_t)grp * g.W.bs1 : (int64_t)z1 * g.W.bs1 + (int64_t)z2 * g.W.bs2;
+  int64_t offA = (int64_t)z1 * g.A.bs1 + (int64_t)z2 * g.A.bs2;
+  int64_t offW = g.goff ? (int64_t)grp * g.W.bs1 : (int64_t)z1 * g.W.bs1 + (int64_t)z2 * g.W.bs2;
+  int K = g.K;
+  if (g.kgoff) {  // weight-gradient mode: this batch reduces over its own K range of the k-strided operands
+    const int k0 = g.kgoff[z];
+    K = g.kgoff[z + 1] - k0;
+    offA += (int64_t)k0 * g.A.ld, offW += (int64_t)k0 * g.W.ld;
+  }
   const int64_t offC = (int64_t)z1 * g.c_bs1 + (int64_t)z2 * g.c_bs2;
   const int64_t offB = g.goff ? (int64_t)grp * g.bias_bs : (int64_t)z * g.bias_bs;
 
@@ -223,9 +229,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (g.K + BK - 1) / BK;
-  ta.load(0, g.K, tid);
-  tw.load(0, g.K, tid);
+  const int nk = (K + BK - 1) / BK;
+  ta.load(0, K, tid);
+  tw.load(0, K, tid);
   ta.store(smem, tid);
   tw.store(smem + NPL * PLANE, tid);
   __syncthreads();
@@ -236,8 +242,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
     uint8_t* nxt = smem + ((kt & 1) ^ 1) * STAGE;
     const bool more = kt + 1 < nk;
     if (more) {
-      ta.load((kt + 1) * BK, g.K, tid);
-      tw.load((kt + 1) * BK, g.K, tid);
+      ta.load((kt + 1) * BK, K, tid);
+      tw.load((kt + 1) * BK, K, tid);
     }
     frag_t a[NPL][4], b[NPL][4];
 #pragma unroll
@@ -375,6 +381,7 @@ int gemm(const GemmArgs& a_in, hipStream_t stream) {
   }
   if (a.A.kind == OP_BF16_ROW) return MDM_ERR_UNSUPPORTED;
   if (a.goff && (a.batch != 1 || a.ngroups <= 0)) return MDM_ERR_ARG;
+  if (a.kgoff && (a.goff || a.A.kind != OP_F32_KSTRIDE || a.W.kind != OP_F32_KSTRIDE)) return MDM_ERR_ARG;
   // plain Linears of the fp32-grade mode: LDS-DMA staged bf16x3 kernel (gemm3.hip); knob 36 keeps the register-staged one
   if (g_bf16_variant != 36 && gemm_x3_dma_eligible(a)) return gemm_x3_dma(a, stream);
   const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);

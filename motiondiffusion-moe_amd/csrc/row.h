@@ -1,0 +1,135 @@
+// One wave (64 lanes) owns one row of D fp32 elements: the register image, LayerNorm and the width dispatch shared by the
+// row-wise kernels (rowwise.hip) and the MoE-block training kernels (moe_train.hip).
+#pragma once
+#include "mdm_common.h"
+#include "mdm_hip.h"
+
+namespace mdm {
+namespace {
+
+constexpr int WPB = 4;  // waves (rows) per 256-thread block
+
+// ---- a row of D floats spread over a wave ------------------------------------------------------
+// VEC: D == 4*64*NV4 exactly, lane holds NV4 float4 (coalesced 16 B/lane); else generic strided scalars.
+template <int NE, bool VEC>
+struct Row {
+  float e[NE];
+  __device__ __forceinline__ void load(const float* __restrict__ p, int D, int lane) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c) {
+        f32x4 v = *(const f32x4*)(p + 4 * (lane + 64 * c));
+        e[4 * c + 0] = v[0], e[4 * c + 1] = v[1], e[4 * c + 2] = v[2], e[4 * c + 3] = v[3];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int i = lane + 64 * j;
+        e[j] = i < D ? p[i] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ p, int D, int lane, int fmt = 1) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c) {
+        const uint2 u = *(const uint2*)(p + 4 * (lane + 64 * c));
+        e[4 * c + 0] = h16_lo_f32(fmt, u.x), e[4 * c + 1] = h16_hi_f32(fmt, u.x);
+        e[4 * c + 2] = h16_lo_f32(fmt, u.y), e[4 * c + 3] = h16_hi_f32(fmt, u.y);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int i = lane + 64 * j;
+        e[j] = i < D ? h16_lo_f32(fmt, (uint32_t)p[i]) : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ p, int D, int lane) const {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c) {
+        f32x4 v = {e[4 * c + 0], e[4 * c + 1], e[4 * c + 2], e[4 * c + 3]};
+        *(f32x4*)(p + 4 * (lane + 64 * c)) = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int i = lane + 64 * j;
+        if (i < D) p[i] = e[j];
+      }
+    }
+  }
+  // bf16 (round-to-nearest-even) copy of the row, for tensors whose only consumer is a bf16 MFMA GEMM
+  __device__ __forceinline__ void store_bf16(uint16_t* __restrict__ p, int D, int lane, int fmt = 1) const {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c)
+        *(uint2*)(p + 4 * (lane + 64 * c)) = make_uint2(pack_h16(fmt, e[4 * c + 0], e[4 * c + 1]), pack_h16(fmt, e[4 * c + 2], e[4 * c + 3]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int i = lane + 64 * j;
+        if (i < D) p[i] = (uint16_t)(pack_h16(fmt, e[j], 0.f) & 0xffff);
+      }
+    }
+  }
+  __device__ __forceinline__ void store_as(void* __restrict__ p, int64_t row, int D, int lane, int bf16) const {
+    if (bf16) {  // format code: 1 = bf16, 2 = fp16
+      store_bf16((uint16_t*)p + row * D, D, lane, bf16);
+    } else {
+      store((float*)p + row * D, D, lane);
+    }
+  }
+  __device__ __forceinline__ float sum() const {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) s += e[j];
+    return wave_sum(s);
+  }
+  // LayerNorm in place (eps 1e-5, biased variance, two-pass like ATen); padded lanes stay 0
+  __device__ __forceinline__ void layernorm(const float* __restrict__ w, const float* __restrict__ b, int D, int lane) {
+    const float mean = sum() / D;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const bool in = VEC || (lane + 64 * j < D);
+      const float d = in ? e[j] - mean : 0.f;
+      s += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(s) / D + 1e-5f);
+    Row<NE, VEC> ww, bb;
+    ww.load(w, D, lane);
+    bb.load(b, D, lane);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const bool in = VEC || (lane + 64 * j < D);
+      e[j] = in ? (e[j] - mean) * rstd * ww.e[j] + bb.e[j] : 0.f;
+    }
+  }
+};
+
+#define MDM_ROW_DISPATCH(D, CALL)                      \
+  do {                                                 \
+    if ((D) == 512) {                                  \
+      CALL(8, true);                                   \
+    } else if ((D) == 1024) {                          \
+      CALL(16, true);                                  \
+    } else if ((D) == 256) {                           \
+      CALL(4, true);                                   \
+    } else if ((D) <= 256) {                           \
+      CALL(4, false);                                  \
+    } else if ((D) <= 1024) {                          \
+      CALL(16, false);                                 \
+    } else {                                           \
+      return MDM_ERR_UNSUPPORTED;                      \
+    }                                                  \
+  } while (0)
+
+inline int row_grid(int64_t M) {
+  int64_t g = (M + WPB - 1) / WPB;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+}  // namespace mdm

@@ -1,0 +1,51 @@
+"""ORACLE (test infrastructure only -- never imported by the product path): reference gradients of the MoE feed-forward
+block by torch autograd through the CPU restatement of the forward (oracle/denoiser_ref.py::moe_ffn, which follows
+text2motion/models/multi_branch.py:52-61, switch_moe.py:44-111 and stylization.py:20-31), the load-balancing loss of
+switch_moe.py:113-145, and the optimizer arithmetic of ddpm_trainer.py:228-244 (clip_grad_norm_ 1.0 + Adam).
+
+Pinning: the forward restated here is the one pinned against the reference-generated goldens (tests/test_oracle_golden.py);
+the gradients are autograd's of that forward, in fp32 (fp64 on request) -- the same thing loss.backward() computes in the
+reference's training loop.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import denoiser_ref as R
+
+
+def lb_loss(usage: torch.Tensor, importance: torch.Tensor, E: int, eps: float = 1e-8) -> torch.Tensor:
+    """switch_moe.py:113-145."""
+    fu = usage / usage.sum().clamp_min(eps)
+    fi = importance / importance.sum().clamp_min(eps)
+    return E * (1.0 - (fu * fi).sum())
+
+
+def moe_ffn_grads(sd: Dict[str, torch.Tensor], prefix: str, E: int, x: torch.Tensor, emb: torch.Tensor, eph_wb, dout: torch.Tensor,
+                  forced=None, dtype=torch.float32):
+    """Returns (out, dx, demb, {state_dict key: gradient}, lb (2,), trace)."""
+    p = {k: v.detach().to(dtype).clone().requires_grad_(v.dtype.is_floating_point and "expert_" not in k)
+         for k, v in sd.items() if k.startswith(prefix + ".")}
+    x = x.detach().to(dtype).clone().requires_grad_(True)
+    emb = emb.detach().to(dtype).clone().requires_grad_(True)
+    eph = None if eph_wb is None else (eph_wb[0].to(dtype), eph_wb[1].to(dtype))
+    trace = {}
+    out = R.moe_ffn(x, emb, p, prefix, E, eph, forced=forced, trace=trace)
+    out.backward(dout.to(dtype))
+    grads = {k: v.grad for k, v in p.items() if v.requires_grad and v.grad is not None}
+    lb = torch.stack([lb_loss(trace[f"{prefix}.branches.{b}.usage"], trace[f"{prefix}.branches.{b}.importance"], E) for b in range(2)])
+    return out.detach(), x.grad, emb.grad, grads, lb.detach(), trace
+
+
+def adam_clip_step(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr=2e-4, betas=(0.9, 0.999),
+                   eps=1e-8, max_norm: Optional[float] = 1.0):
+    """clip_grad_norm_ + torch.optim.Adam arithmetic on flat fp32 tensors (returns new params, m, v, the gradient norm)."""
+    g = grads.clone()
+    norm = g.norm()
+    if max_norm is not None and max_norm > 0:
+        g = g * torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    m = betas[0] * m + (1 - betas[0]) * g
+    v = betas[1] * v + (1 - betas[1]) * g * g
+    bc1, bc2 = 1 - betas[0] ** step, 1 - betas[1] ** step
+    params = params - lr * (m / bc1) / ((v / bc2).sqrt() + eps)
+    return params, m, v, norm
