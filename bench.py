@@ -302,6 +302,7 @@ def main():
                     help="cfg = guided DDPM step (2 forwards batched; configs[1], [2]); ddim = DDIM step (1 forward; configs[3])")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
     ap.add_argument("--frames", type=int, default=196)
+    ap.add_argument("--text-tokens", type=int, default=28, help="text tokens per caption (the reference pads to 8 + 77 = 85)")
     ap.add_argument("--schedule", type=int, default=1000)
     ap.add_argument("--cfg-scale", type=float, default=7.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -324,7 +325,7 @@ def main():
 
     if a.variant:
         importlib.import_module("motiondiffusion-moe_amd._lib").lib().mdm_set_gemm_variant(a.variant)
-    B, T, N = a.batch, a.frames, 28
+    B, T, N = a.batch, a.frames, a.text_tokens
     m, inputs, host = build_model(a.config, dev, a.precision, B, T, N, seed=0)
     x, length, xf_proj, xf_out = inputs
     diff = D_.GaussianDiffusion(betas=D_.get_named_beta_schedule("linear", a.schedule),

@@ -213,9 +213,9 @@ typedef struct MdmTextCache {
   int32_t B, N;
   /* optional (all three or none; throughput mode, D == 512, H * N <= 128): the query / output projections of the text
    * cross-attention folded into the text side, see csrc/sdfold.hip.  Zero-initialised by the caller (padding). */
-  uint16_t* sd_kfold; /* bf16 [2L, B, 128, D]   K'[h*N + n, :] = key_h[n, :] Wq_h / sqrt(dh) */
-  float* sd_cb;       /* fp32 [2L, B, 128]      key_h[n, :] . bq_h / sqrt(dh) */
-  uint16_t* sd_vfold; /* bf16 [2L, B, D, 128]   V'^T[:, h*N + n] = Wout[:, h] value_h[n, :]^T */
+  uint16_t* sd_kfold; /* 16-bit [2L, B, P, 128, D]  K'[hs*N + n, :] = key_h[n, :] Wq_h / sqrt(dh); P = mdm_sd_fold_passes, hs = h mod heads-per-pass */
+  float* sd_cb;       /* fp32   [2L, B, P, 128]     key_h[n, :] . bq_h / sqrt(dh) */
+  uint16_t* sd_vfold; /* 16-bit [2L, B, P, D, 128]  V'^T[:, hs*N + n] = Wout[:, h] value_h[n, :]^T */
 } MdmTextCache;
 
 /* Optional per-loop stem cache: the time-embedding chain (time.py:15-31 -> time_embed -> time_proj -> gated_fusion.proj_time,
@@ -390,6 +390,11 @@ int mdm_probe_enable(int32_t enable);
  * forced_routing: int32 [2L][2 branches][B*S_layer (padded to B*T)][2] (mdm_block_forward(MDM_BLOCK_MOE): one layer's worth).
  * Used to count routing flips against the oracle; pass NULL to switch it off. */
 int mdm_route_dump(int32_t* buf);
+/* Number of passes (of <= 128 folded text columns, whole heads) the fused text cross-attention takes for H heads and N text
+ * tokens, 0 when the folded path is not taken (D != 512, or more than two passes: N > 64 at H = 4, where the GEMM chain
+ * measures faster).  Sizes the optional MdmTextCache buffers:
+ * sd_kfold [2L][B][passes][128][D] (16-bit), sd_cb [2L][B][passes][128] (fp32), sd_vfold [2L][B][passes][D][128] (16-bit). */
+int mdm_sd_fold_passes(int32_t D, int32_t H, int32_t N);
 int mdm_probe_read(float* us, int32_t* rows, int32_t cap);
 
 const char* mdm_version(void);

@@ -58,6 +58,8 @@ int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, 
               int h16, hipStream_t s);
 // sdfold.hip: text cross-attention with folded projections + the following LayerNorm, one launch
 bool sd_fold_supported(int D, int H, int N);
+int sd_fold_heads_per_pass(int H, int N);  // whole heads per pass of <= 128 folded columns
+int sd_fold_passes(int H, int N);
 int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const uint16_t* vfold, const float* bout,
             const float* ln_w, const float* ln_b, int B, int S, int D, int H, int N, float* out32, uint16_t* out16,
             int h16, hipStream_t s);

@@ -427,6 +427,16 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
   return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, false);
 }
 
+// Passes the folded text cross-attention (csrc/sdfold.hip) takes, 0 = use the GEMM chain.  Measured end to end (configs[1],
+// ms per step, folded / chain): N = 28: 6.09 / 6.28, N = 40: 6.16 / 6.27, N = 64: 6.21 / 6.29 (two passes), N = 85: 6.40 / 6.31
+// (four passes: each pass re-streams the x tile and restarts the K' pipeline) -- so the fold is taken up to two passes; knob 24
+// forces it at any supported N (tests).
+int sd_fold_policy(int D, int H, int N) {
+  if (!sd_fold_supported(D, H, N)) return 0;
+  const int np = sd_fold_passes(H, N);
+  return (np <= 2 || g_bf16_variant == 24) ? np : 0;
+}
+
 // MemoryEfficientCrossAttentionBlock (fast_attention.py:301-330); out must not alias x
 struct SdFold {  // folded text side of one layer (MdmTextCache.sd_kfold / sd_cb / sd_vfold), or nulls
   const uint16_t* kfold = nullptr;
@@ -439,7 +449,7 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H, N = c.N;
   const Work& w = c.w;
-  if (c.bf && fold.kfold && g_bf16_variant != 22 && sd_fold_supported(D, H, N)) {
+  if (c.bf && fold.kfold && g_bf16_variant != 22 && sd_fold_policy(D, H, N) > 0) {
     // throughput mode: query GEMM + attention core + output GEMM + LayerNorm in one launch (csrc/sdfold.hip)
     MDM_TRY(sd_fold(x16, fold.kfold, fold.cb, fold.vfold, l.sd_out_b, l.sd_ln_w, l.sd_ln_b, c.B, c.S, D, H, N, w.t3,
                     (uint16_t*)w.t4, c.h16, c.s));
@@ -511,10 +521,11 @@ const float* tc_v(const MdmModel& m, const MdmTextCache& tc, int layer) {
 }
 SdFold tc_fold(const MdmModel& m, const MdmTextCache& tc, int layer) {
   SdFold f;
-  if (tc.sd_kfold && tc.sd_cb && tc.sd_vfold) {
-    f.kfold = tc.sd_kfold + (int64_t)layer * tc.B * 128 * m.D;
-    f.cb = tc.sd_cb + (int64_t)layer * tc.B * 128;
-    f.vfold = tc.sd_vfold + (int64_t)layer * tc.B * m.D * 128;
+  if (tc.sd_kfold && tc.sd_cb && tc.sd_vfold) {  // per layer: [B][passes][128][D], [B][passes][128], [B][passes][D][128]
+    const int64_t np = sd_fold_passes(m.H, tc.N);
+    f.kfold = tc.sd_kfold + (int64_t)layer * tc.B * np * 128 * m.D;
+    f.cb = tc.sd_cb + (int64_t)layer * tc.B * np * 128;
+    f.vfold = tc.sd_vfold + (int64_t)layer * tc.B * np * m.D * 128;
   }
   return f;
 }
@@ -668,47 +679,51 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
     MDM_TRY(linear(c, act_f32(xf_out), BN, m->Dt, l.sd_v, l.sd_v_b, D, (float*)tc_v(*m, *tc, layer), nullptr));
     if (tc->sd_kfold && tc->sd_cb && tc->sd_vfold) {
       // fold the query / output projections into the text side (csrc/sdfold.hip), fp32-grade arithmetic, bf16 results
-      if (!l.sd_q_w32 || !l.sd_out_w32 || H * N > 128) return MDM_ERR_ARG;
+      if (!l.sd_q_w32 || !l.sd_out_w32 || sd_fold_policy(D, H, N) <= 0) return MDM_ERR_ARG;
       const SdFold f = tc_fold(*m, *tc, layer);
       const float scale = 1.f / sqrtf((float)dh);
       const float* kc = tc_k(*m, *tc, layer);
       const float* vc = tc_v(*m, *tc, layer);
-      {  // K'[b][h*N + n][j] = scale * sum_d key[b,n,h*dh+d] Wq[h*dh+d, j]
-        GemmArgs g = gemm_defaults(3);
-        g.A = op_f32(kc, D);
-        g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
-        g.W = op_f32_kstride(l.sd_q_w32, D);
-        g.W.bs1 = 0, g.W.bs2 = (int64_t)dh * D;
-        g.M = N, g.N = D, g.K = dh;
-        g.batch = B * H, g.nb2 = H;
-        g.alpha = scale;
-        g.h16 = c.h16;
-        g.C16 = (uint16_t*)f.kfold, g.ldc = D, g.c_bs1 = (int64_t)128 * D, g.c_bs2 = (int64_t)N * D;
-        MDM_TRY(gemm(g, c.s));
-      }
-      {  // cb[b][h*N + n] = scale * key[b,n,h*dh:] . bq[h*dh:]
-        GemmArgs g = gemm_defaults(3);
-        g.A = op_f32(kc, D);
-        g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
-        g.W = op_f32(l.sd_q_b, dh);
-        g.W.bs1 = 0, g.W.bs2 = dh;
-        g.M = N, g.N = 1, g.K = dh;
-        g.batch = B * H, g.nb2 = H;
-        g.alpha = scale;
-        g.C = (float*)f.cb, g.ldc = 1, g.c_bs1 = 128, g.c_bs2 = N;
-        MDM_TRY(gemm(g, c.s));
-      }
-      {  // V'^T[b][j][h*N + n] = sum_d Wout[j, h*dh+d] value[b,n,h*dh+d]
-        GemmArgs g = gemm_defaults(3);
-        g.A = op_f32(l.sd_out_w32, D);
-        g.A.bs1 = 0, g.A.bs2 = dh;
-        g.W = op_f32(vc, D);
-        g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
-        g.M = D, g.N = N, g.K = dh;
-        g.batch = B * H, g.nb2 = H;
-        g.h16 = c.h16;
-        g.C16 = (uint16_t*)f.vfold, g.ldc = 128, g.c_bs1 = (int64_t)D * 128, g.c_bs2 = N;
-        MDM_TRY(gemm(g, c.s));
+      const int hpp = sd_fold_heads_per_pass(H, N), np = sd_fold_passes(H, N);
+      for (int ps = 0; ps < np; ++ps) {  // one pass = hc whole heads, packed as rows / columns hs * N + n of a 128-wide image
+        const int h0 = ps * hpp, hc = (H - h0) < hpp ? (H - h0) : hpp;
+        {  // K'[b][ps][hs*N + n][j] = scale * sum_d key[b,n,h*dh+d] Wq[h*dh+d, j]
+          GemmArgs g = gemm_defaults(3);
+          g.A = op_f32(kc + h0 * dh, D);
+          g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
+          g.W = op_f32_kstride(l.sd_q_w32 + (int64_t)h0 * dh * D, D);
+          g.W.bs1 = 0, g.W.bs2 = (int64_t)dh * D;
+          g.M = N, g.N = D, g.K = dh;
+          g.batch = B * hc, g.nb2 = hc;
+          g.alpha = scale;
+          g.h16 = c.h16;
+          g.C16 = (uint16_t*)f.kfold + (int64_t)ps * 128 * D, g.ldc = D, g.c_bs1 = (int64_t)np * 128 * D, g.c_bs2 = (int64_t)N * D;
+          MDM_TRY(gemm(g, c.s));
+        }
+        {  // cb[b][ps][hs*N + n] = scale * key[b,n,h*dh:] . bq[h*dh:]
+          GemmArgs g = gemm_defaults(3);
+          g.A = op_f32(kc + h0 * dh, D);
+          g.A.bs1 = (int64_t)N * D, g.A.bs2 = dh;
+          g.W = op_f32(l.sd_q_b + h0 * dh, dh);
+          g.W.bs1 = 0, g.W.bs2 = dh;
+          g.M = N, g.N = 1, g.K = dh;
+          g.batch = B * hc, g.nb2 = hc;
+          g.alpha = scale;
+          g.C = (float*)f.cb + ps * 128, g.ldc = 1, g.c_bs1 = (int64_t)np * 128, g.c_bs2 = N;
+          MDM_TRY(gemm(g, c.s));
+        }
+        {  // V'^T[b][ps][j][hs*N + n] = sum_d Wout[j, h*dh+d] value[b,n,h*dh+d]
+          GemmArgs g = gemm_defaults(3);
+          g.A = op_f32(l.sd_out_w32 + h0 * dh, D);
+          g.A.bs1 = 0, g.A.bs2 = dh;
+          g.W = op_f32(vc + h0 * dh, D);
+          g.W.bs1 = (int64_t)N * D, g.W.bs2 = dh;
+          g.M = D, g.N = N, g.K = dh;
+          g.batch = B * hc, g.nb2 = hc;
+          g.h16 = c.h16;
+          g.C16 = (uint16_t*)f.vfold + (int64_t)ps * D * 128, g.ldc = 128, g.c_bs1 = (int64_t)np * D * 128, g.c_bs2 = N;
+          MDM_TRY(gemm(g, c.s));
+        }
       }
     }
   }
@@ -949,6 +964,10 @@ int mdm_motion_postprocess(const float* motion, const int32_t* length, const flo
   return motion_post(motion, length, mean, std, B, T, feats, joints, radius, weights, scratch, joints_out,
                      (hipStream_t)stream);
 }
+
+// passes of <= 128 folded text columns that sd_fold takes for (H heads, N text tokens); 0 = unsupported: sizes the
+// MdmTextCache.sd_kfold / sd_cb / sd_vfold buffers ([L2][B][passes][128][D], [L2][B][passes][128], [L2][B][passes][D][128])
+int mdm_sd_fold_passes(int32_t D, int32_t H, int32_t N) { return sd_fold_policy(D, H, N); }
 
 int mdm_route_dump(int32_t* buf) {
   g_route_dump = buf;

@@ -5,7 +5,10 @@
 // K_h, V_h depend only on the text, so both projections fold into per-text matrices (built once per caption batch by
 // mdm_text_cache_build):   K'[h n, :] = K_h[n, :] Wq_h / sqrt(dh),   cb[h n] = K_h[n, :] . bq_h / sqrt(dh),
 //                          V'[h n, :] = V_h[n, :] Wout[:, h]^T
-// and the block becomes   out = softmax_n( x K'^T + cb ) V' + bout   -- two small GEMMs with H*N <= 128 "hidden" columns.
+// and the block becomes   out = softmax_n( x K'^T + cb ) V' + bout   -- two small GEMMs with H*N "hidden" columns, taken in
+// passes of <= 128 columns (whole heads: hpp = min(H, 128 / N) heads per pass; one pass up to N = 32 text tokens at H = 4, two
+// up to 64, four up to 128 -- the reference pads captions to 8 + 77 = 85 tokens, text_encoder.py:19,26); the output
+// accumulators stay in registers across the passes.
 // This kernel does that and the LayerNorm that follows (ffn.0, fast_attention.py:293,329) in ONE launch instead of four
 // (query GEMM, attention core, output GEMM, LayerNorm): a workgroup of 8 waves owns <= 64 rows of one sample and all 512
 // output columns, so the row statistics are local.
@@ -40,7 +43,8 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
                                                      const float* __restrict__ cb, const uint16_t* __restrict__ vfold,
                                                      const float* __restrict__ bout, const float* __restrict__ ln_w,
                                                      const float* __restrict__ ln_b, float* __restrict__ out32,
-                                                     uint16_t* __restrict__ out16, int S, int H, int N, int ntile, int rpt) {
+                                                     uint16_t* __restrict__ out16, int S, int H, int N, int ntile, int rpt, int hpp,
+                                                     int npass) {
   typedef typename HT::frag_t frag_t;
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   uint8_t* ring = smem;
@@ -56,14 +60,11 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
   if (nrows <= 0) return;
   const int64_t row0 = (int64_t)b * S + t0;
 
-  // zero the probability image (its columns >= H*N stay zero: they multiply the zero padding of V')
-  *(uint4*)(pim + tid * 32) = make_uint4(0, 0, 0, 0);
-  *(uint4*)(pim + tid * 32 + 16) = make_uint4(0, 0, 0, 0);
-
   // ---- phase 1 sources: 24 pieces of 8 rows x 128 B per stage (8 of x, 16 of K'), 3 per wave --------------------
   const int sub8 = lane >> 3, c8 = ((lane & 7) ^ sub8) * 8;
   const uint16_t* src[3];
   int dst[3];
+  int64_t kfoff[3];  // K' pieces: element offset inside one pass's [128][512] image (x pieces: -1)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int p = 3 * wid + i;
@@ -72,12 +73,33 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
       r = r < nrows ? r : nrows - 1;
       src[i] = x16 + (row0 + r) * FD + c8;
       dst[i] = p * 1024;
+      kfoff[i] = -1;
     } else {
       const int r = (p - 8) * 8 + sub8;
-      src[i] = kfold + ((int64_t)b * HNP + r) * FD + c8;
+      src[i] = nullptr;
+      kfoff[i] = (int64_t)r * FD + c8;
       dst[i] = BM * 128 + (p - 8) * 1024;
     }
   }
+  f32x4 o[4][4];
+#pragma unroll
+  for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[sidx][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+  const int hcnt = (H - pass * hpp) < hpp ? (H - pass * hpp) : hpp;  // heads of this pass
+  const uint16_t* kf_p = kfold + ((int64_t)b * npass + pass) * HNP * FD;
+  const float* cb_p = cb + ((int64_t)b * npass + pass) * HNP;
+  const uint16_t* vf_p = vfold + ((int64_t)b * npass + pass) * FD * HNP;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (kfoff[i] >= 0) src[i] = kf_p + kfoff[i];
+  // zero the probability image (its columns >= hcnt * N stay zero: they multiply the zero padding of V'); the previous
+  // pass's readers are behind the barrier that ends it
+  *(uint4*)(pim + tid * 32) = make_uint4(0, 0, 0, 0);
+  *(uint4*)(pim + tid * 32 + 16) = make_uint4(0, 0, 0, 0);
   auto stage1 = [&](int kt) {
     uint8_t* s = ring + (kt % NST) * ST_B;
 #pragma unroll
@@ -114,7 +136,7 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
   }
   {
     const int n0 = 16 * wid + 4 * q;
-    const f32x4 cbv = *(const f32x4*)(cb + (int64_t)b * HNP + n0);
+    const f32x4 cbv = *(const f32x4*)(cb_p + n0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 v = acc[i];
@@ -128,7 +150,7 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
   const uint16_t* vsrc;
   {
     const int r = 16 * wid + (lane >> 4);  // + 4 * i
-    vsrc = vfold + ((int64_t)b * FD + r) * HNP;
+    vsrc = vf_p + (int64_t)r * HNP;
   }
   auto slab = [&](int sidx) {
     uint8_t* s = ring + (sidx % 3) * SLAB_B;
@@ -141,19 +163,28 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
   slab(0), slab(1), slab(2);
 
   // ---- softmax over each head's N key columns (fast_attention.py:318), probabilities as bf16 -----------------------
-  if (tid < BM * H) {
-    const int row = tid / H, h = tid - row * H;
+  {
+    // G lanes per (row, head), a power of two with 64 * hcnt * G <= 512 threads: 8 with one head in the pass, 4 with two,
+    // 2 with three or four, 1 beyond
+    const int gq = 8 / hcnt;
+    const int G = gq >= 8 ? 8 : (gq >= 4 ? 4 : (gq >= 2 ? 2 : 1));
+    const int unit = tid / G, sub = tid - unit * G;
+    const bool on = unit < BM * hcnt;
+    const int row = on ? unit / hcnt : 0, h = on ? unit - row * hcnt : 0;
     const float* p = sc + row * SC_LD + h * N;
     float mx = -INFINITY;
-    for (int i = 0; i < N; ++i) mx = fmaxf(mx, p[i]);
+    for (int i = sub; i < N; i += G) mx = fmaxf(mx, p[i]);
+    for (int o2 = 1; o2 < G; o2 <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
     float sum = 0.f;
-    for (int i = 0; i < N; ++i) sum += exp_fast(p[i] - mx);
+    for (int i = sub; i < N; i += G) sum += exp_fast(p[i] - mx);
+    for (int o2 = 1; o2 < G; o2 <<= 1) sum += __shfl_xor(sum, o2, 64);
     const float inv = 1.f / sum;
-    for (int i = 0; i < N; ++i) {
-      const int c = h * N + i;
-      const float e = exp_fast(p[i] - mx) * inv;
-      *(uint16_t*)(pim + row * 256 + ((((c >> 3) ^ (row & 15))) << 4) + (c & 7) * 2) = (uint16_t)(HT::pack(e, 0.f) & 0xffff);
-    }
+    if (on)
+      for (int i = sub; i < N; i += G) {
+        const int c = h * N + i;
+        const float e = exp_fast(p[i] - mx) * inv;
+        *(uint16_t*)(pim + row * 256 + ((((c >> 3) ^ (row & 15))) << 4) + (c & 7) * 2) = (uint16_t)(HT::pack(e, 0.f) & 0xffff);
+      }
   }
   __syncthreads();
 
@@ -166,11 +197,8 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
       const int ra = 16 * i + r16;
       pf[ks][i] = *(const frag_t*)(pim + ra * 256 + (((ks * 4 + q) ^ (ra & 15)) << 4));
     }
-  f32x4 o[4][4];
 #pragma unroll
   for (int sidx = 0; sidx < 4; ++sidx) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[sidx][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // slabs 0..2 were issued together (4 pieces each per wave), slab 3 after slab 0's slot was released
     if (sidx == 0) {
       wait_vm<8>();
@@ -192,6 +220,9 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
       for (int i = 0; i < 4; ++i) o[sidx][i] = HT::mfma16(vf, pf[ks][i], o[sidx][i]);
     }
   }
+
+  __syncthreads();  // every wave is done with this pass's slabs and probability image
+  }  // pass
 
   // ---- epilogue: + bout, LayerNorm over the 512 columns (two passes through LDS across the 8 waves) -------------------
   // lane: rows m = 16 i + r16 (i < 4), columns j = 128 s + 16 w + 4 q + r
@@ -256,7 +287,16 @@ __global__ __launch_bounds__(NT) void sd_fold_kernel(const uint16_t* __restrict_
 
 }  // namespace
 
-bool sd_fold_supported(int D, int H, int N) { return D == FD && H >= 1 && H <= 8 && N >= 1 && H * N <= HNP; }
+bool sd_fold_supported(int D, int H, int N) { return D == FD && H >= 1 && H <= 8 && N >= 1 && N <= HNP; }
+// heads per pass / number of passes of <= 128 folded columns
+int sd_fold_heads_per_pass(int H, int N) {
+  const int hpp = HNP / (N > 0 ? N : 1);
+  return hpp < 1 ? 1 : (hpp > H ? H : hpp);
+}
+int sd_fold_passes(int H, int N) {
+  const int hpp = sd_fold_heads_per_pass(H, N);
+  return (H + hpp - 1) / hpp;
+}
 
 int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const uint16_t* vfold, const float* bout,
             const float* ln_w, const float* ln_b, int B, int S, int D, int H, int N, float* out32, uint16_t* out16,
@@ -271,12 +311,13 @@ int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const u
     attr = true;
   }
   const int ntile = (S + BM - 1) / BM, rpt = (S + ntile - 1) / ntile;
+  const int hpp = sd_fold_heads_per_pass(H, N), npass = sd_fold_passes(H, N);
   if (h16 == MDM_H16_F16) {
     hipLaunchKernelGGL(sd_fold_kernel<HF>, dim3(B * ntile), dim3(NT), SMEM_B, s, x16, kfold, cb, vfold, bout, ln_w, ln_b,
-                       out32, out16, S, H, N, ntile, rpt);
+                       out32, out16, S, H, N, ntile, rpt, hpp, npass);
   } else {
     hipLaunchKernelGGL(sd_fold_kernel<HB>, dim3(B * ntile), dim3(NT), SMEM_B, s, x16, kfold, cb, vfold, bout, ln_w, ln_b,
-                       out32, out16, S, H, N, ntile, rpt);
+                       out32, out16, S, H, N, ntile, rpt, hpp, npass);
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;

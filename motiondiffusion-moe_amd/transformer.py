@@ -300,12 +300,14 @@ class MotionTransformer(nn.Module):
         tc = L.TextCache()
         tc.lin_at, tc.sd_k, tc.sd_v, tc.B, tc.N = at.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, N
         fold = ()
-        if self.precision in (L.PREC_BF16, L.PREC_F16, L.PREC_FP8) and D == 512 and H * N <= 128:
-            # throughput modes: query / output projections of the text cross-attention folded into the text side
+        npass = L.lib().mdm_sd_fold_passes(D, H, N) if self.precision in (L.PREC_BF16, L.PREC_F16, L.PREC_FP8) else 0
+        if npass > 0:
+            # throughput modes: query / output projections of the text cross-attention folded into the text side, in passes
+            # of <= 128 folded columns (one pass up to N = 32 text tokens, four at the reference's 85)
             h16 = torch.bfloat16 if self.precision == L.PREC_BF16 else torch.float16
-            fold = (torch.zeros((L2, B, 128, D), dtype=h16, device=dev),
-                    torch.zeros((L2, B, 128), dtype=torch.float32, device=dev),
-                    torch.zeros((L2, B, D, 128), dtype=h16, device=dev))
+            fold = (torch.zeros((L2, B, npass, 128, D), dtype=h16, device=dev),
+                    torch.zeros((L2, B, npass, 128), dtype=torch.float32, device=dev),
+                    torch.zeros((L2, B, npass, D, 128), dtype=h16, device=dev))
             tc.sd_kfold, tc.sd_cb, tc.sd_vfold = (t.data_ptr() for t in fold)
         ws = self._workspace(B, 2, N)
         with torch.cuda.device(dev):  # launches go to the current stream OF THE MODEL'S DEVICE, whatever device is current
