@@ -120,7 +120,8 @@ class DDPMTrainer(object):
         return ckpt["ep"], ckpt.get("total_it", 0)
 
     def train(self, *a, **k):
-        raise NotImplementedError("training is outside this build's scope (SURVEY.md §8f): only the sampling API "
-                                  "of DDPMTrainer is provided")
+        raise NotImplementedError("whole-model training is outside this build's scope (SURVEY.md section 8(f)): DDPMTrainer "
+                                  "provides the sampling API; the training step of the MoE feed-forward block is "
+                                  "moe_train.MoEFFNTrainer")
 
     forward = backward_G = update = train
