@@ -52,6 +52,7 @@ int perf_attn256(const void* qkv, int h16, const uint16_t* PT, int ldp, const fl
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
 // fused text cross-attention cores (xattn.hip), head_dim 128
 bool xattn_supported(int dh, int N);
+bool lin_xattn_supported(int dh);  // linear cross-attention core: head_dim 128 or 256
 int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
             float* out32, int h16, hipStream_t s);
 int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,

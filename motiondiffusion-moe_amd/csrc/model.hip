@@ -298,7 +298,7 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
   const int D = m.D, H = m.H, dh = D / H;
   const Work& w = c.w;
   if (!pre_normed) MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
-  const bool fused = c.bf && xattn_supported(dh, 1);
+  const bool fused = c.bf && lin_xattn_supported(dh) && !(dh == 256 && g_bf16_variant == 23);  // knob 23: big-width generic paths
   bool x16o = false;
   MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
   if (fused) {

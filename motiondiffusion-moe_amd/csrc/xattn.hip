@@ -198,9 +198,90 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
   }
 }
 
+// the same at head_dim 256 (big model): A^T [256][264] fills 132 KiB of LDS (dynamic), 64 elements of q per lane
+constexpr int DH2 = 256, PS2 = 264;
+template <typename HT, bool IN16>
+__global__ __launch_bounds__(XNT, 2) void lin_xattn256_kernel(const void* __restrict__ ql, const float* __restrict__ at, int S,
+                                                              int H, float* __restrict__ out, uint16_t* __restrict__ out16) {
+  typedef typename HT::frag_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) uint16_t aL2[];  // A^T [l][d], row stride PS2
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH2;
+  const float* ab = at + (int64_t)blockIdx.x * DH2 * DH2;
+  for (int i = tid; i < DH2 * (DH2 / 4); i += XNT) {
+    const int l = i / (DH2 / 4), c = i - l * (DH2 / 4);
+    const f32x4 v = *(const f32x4*)(ab + l * DH2 + 4 * c);
+    *(uint2*)(aL2 + l * PS2 + 4 * c) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
+  }
+  __syncthreads();
+  const int ntile = (S + 15) >> 4;
+  for (int tile = wid; tile < ntile; tile += XNT / 64) {
+    const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
+    float x[64];  // k = 32 ks + 8 q + j
+    if constexpr (IN16) {
+      const uint16_t* p = (const uint16_t*)ql + ((int64_t)b * S + tc) * D + h * DH2 + 8 * q;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const uint4 u = *(const uint4*)(p + 32 * ks);
+        x[8 * ks + 0] = HT::lo(u.x), x[8 * ks + 1] = HT::hi(u.x), x[8 * ks + 2] = HT::lo(u.y), x[8 * ks + 3] = HT::hi(u.y);
+        x[8 * ks + 4] = HT::lo(u.z), x[8 * ks + 5] = HT::hi(u.z), x[8 * ks + 6] = HT::lo(u.w), x[8 * ks + 7] = HT::hi(u.w);
+      }
+    } else {
+      const float* p = (const float*)ql + ((int64_t)b * S + tc) * D + h * DH2 + 8 * q;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
+      }
+    }
+    float mx = -INFINITY;  // softmax over head_dim (:248)
+#pragma unroll
+    for (int i = 0; i < 64; ++i) mx = fmaxf(mx, x[i]);
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      x[i] = exp_fast(x[i] - mx);
+      sum += x[i];
+    }
+    const float inv = 1.f / quad_sum(sum);
+    frag_t qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[8 * ks + j] *= inv;
+      qf[ks] = make_frag<HT>(x + 8 * ks);
+    }
+    f32x4 y[16];
+#pragma unroll
+    for (int lt = 0; lt < 16; ++lt) y[lt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int lt = 0; lt < 16; ++lt) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const frag_t af = *(const frag_t*)(aL2 + (16 * lt + r16) * PS2 + 32 * ks + 8 * q);
+        y[lt] = HT::mfma16(af, qf[ks], y[lt]);  // D[l][t]
+      }
+      if ((lt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t < S && out16) {
+      uint16_t* orow = out16 + ((int64_t)b * S + t) * D + h * DH2;
+#pragma unroll
+      for (int lt = 0; lt < 16; ++lt)
+        *(uint2*)(orow + 16 * lt + 4 * q) = make_uint2(HT::pack(y[lt][0], y[lt][1]), HT::pack(y[lt][2], y[lt][3]));
+    } else if (t < S) {
+      float* orow = out + ((int64_t)b * S + t) * D + h * DH2;
+#pragma unroll
+      for (int lt = 0; lt < 16; ++lt) *(f32x4*)(orow + 16 * lt + 4 * q) = y[lt];
+    }
+  }
+}
+
 }  // namespace
 
 bool xattn_supported(int dh, int N) { return dh == DH && N >= 1 && N <= NP; }
+bool lin_xattn_supported(int dh) { return dh == DH || dh == DH2; }
 
 // q_fmt: 0 = fp32 q rows, 1 / 2 = bf16 / fp16 rows; h16: operand format of the MFMAs and of out16 (MDM_H16_*)
 int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
@@ -232,9 +313,34 @@ int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, i
 
 int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
               int h16, hipStream_t s) {
-  if (dh != DH) return MDM_ERR_UNSUPPORTED;
+  if (dh != DH && dh != DH2) return MDM_ERR_UNSUPPORTED;
   if (!ql || !at || (!out && !out16) || (ql_fmt && ql_fmt != h16)) return MDM_ERR_ARG;
   const dim3 grid(B * H), block(XNT);
+  if (dh == DH2) {
+    constexpr int smem = DH2 * PS2 * 2;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)lin_xattn256_kernel<HF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+          hipFuncSetAttribute((const void*)lin_xattn256_kernel<HF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+          hipFuncSetAttribute((const void*)lin_xattn256_kernel<HB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+          hipFuncSetAttribute((const void*)lin_xattn256_kernel<HB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        return MDM_ERR_LAUNCH;
+      attr = true;
+    }
+    if (h16 == MDM_H16_F16) {
+      if (ql_fmt) {
+        hipLaunchKernelGGL((lin_xattn256_kernel<HF, true>), grid, block, smem, s, ql, at, S, H, out, out16);
+      } else {
+        hipLaunchKernelGGL((lin_xattn256_kernel<HF, false>), grid, block, smem, s, ql, at, S, H, out, out16);
+      }
+    } else if (ql_fmt) {
+      hipLaunchKernelGGL((lin_xattn256_kernel<HB, true>), grid, block, smem, s, ql, at, S, H, out, out16);
+    } else {
+      hipLaunchKernelGGL((lin_xattn256_kernel<HB, false>), grid, block, smem, s, ql, at, S, H, out, out16);
+    }
+    MDM_RETURN_IF_LAUNCH_FAILED();
+    return MDM_OK;
+  }
   if (h16 == MDM_H16_F16) {
     if (ql_fmt) {
       hipLaunchKernelGGL((lin_xattn_kernel<HF, true>), grid, block, 0, s, ql, at, S, H, out, out16);

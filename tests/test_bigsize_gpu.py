@@ -214,3 +214,55 @@ def test_big_width_performer_core_fused_kernel(S, precision, tol):
         e_f, e_c = rel_inf(fused, ref), rel_inf(chain, ref)
         print(f"big performer {slot} S={S} precision {precision}: fused {e_f:.2e}, GEMM-composed chain {e_c:.2e}")
         assert e_f < tol and not torch.equal(fused, chain)
+
+
+@pytest.mark.parametrize("precision,tol", [(2, 6e-3), (1, 3e-2)])
+@pytest.mark.parametrize("S,N", [(196, 28), (98, 9), (37, 85)])
+def test_big_width_linear_cross_attention_fused_core(S, N, precision, tol):
+    """head_dim 256: GatedCrossAttention (fast_attention.py:242-272) through mdm_block_forward runs the fused
+    softmax_dh(q) A core of csrc/xattn.hip (lin_xattn256_kernel: A^T of one (batch, head) resident in 132 KiB of LDS) in the
+    16-bit modes; knob 23 selects the GEMM-composed path (head softmax + batched GEMM) on the same inputs."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from conftest import build_module, load_golden
+    g, meta = load_golden("fwd_big_dims")
+    m, (sd, eph, proj, mcfg) = build_module(meta, precision=precision)
+    L, synth = pkg("_lib"), pkg("synth")
+    lib, pm = L.lib(), m.pack()
+    D, H, B = 1024, 4, 2
+    Dt = sd["decoder_blocks_low.0.module.cross_attn.base_ca.key.weight"].shape[1]
+    h = synth.uniform_pm1((B, S, D), "blk.h", S) * 1.5
+    emb = synth.uniform_pm1((B, D), "blk.emb", S)
+    xf = synth.uniform_pm1((B, N, Dt), "blk.xf", N) * 1.7
+    length = torch.tensor([S, max(1, S - 13)])
+    pre = "decoder_blocks_low.0.module"
+    sc = []
+    for slot, sp in (("local_style", pre + ".dual_self_attn.local_attn.style_block"),
+                     ("global_style", pre + ".dual_self_attn.global_attn.style_block"),
+                     ("cross_style", pre + ".cross_attn.base_ca.proj_out"), ("ffn_style", pre + ".ffn.proj_out")):
+        w, b = eph["low.0." + slot]
+        sc.append(F.linear(F.silu(F.linear(emb, w, b)), sd[sp + ".emb_layers.1.weight"], sd[sp + ".emb_layers.1.bias"]))
+    sc = torch.stack(sc)
+    tcache = m.prepare_text(xf.cuda())
+    ws = m._workspace(B, S, N)
+    hd, scd, ld = h.cuda().contiguous(), sc.cuda().contiguous(), length.to(torch.int32).cuda()
+
+    def run():
+        out = torch.empty_like(hd)
+        L.check(lib.mdm_block_forward(C.byref(pm.model), C.c_int32(0), C.c_int32(L.BLOCK_CROSS), C.byref(tcache["tc"]),
+                                      C.c_void_p(hd.data_ptr()), C.c_void_p(scd.data_ptr()), C.c_void_p(ld.data_ptr()),
+                                      C.c_int32(B), C.c_int32(S), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                      C.c_int64(ws.numel()), C.c_void_p(0), C.c_int32(precision), C.c_void_p(L.stream_ptr())))
+        return out.cpu()
+
+    fused = run()
+    lib.mdm_set_gemm_variant(23)
+    try:
+        chain = run()
+    finally:
+        lib.mdm_set_gemm_variant(0)
+    with torch.no_grad():
+        ref = R.gated_cross_attention(h, xf, emb, sd, pre + ".cross_attn", H, eph["low.0.cross_style"])
+    e_f, e_c = rel_inf(fused, ref), rel_inf(chain, ref)
+    print(f"big linear cross-attention S={S} N={N} precision {precision}: fused {e_f:.2e}, GEMM-composed {e_c:.2e}")
+    assert e_f < tol and not torch.equal(fused, chain)
