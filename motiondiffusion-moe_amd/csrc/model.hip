@@ -463,11 +463,11 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
   {
     LinOpts o;
     o.alpha = 1.f / sqrtf((float)dh);
-    const bool fz = c.bf && xattn_supported(dh, N);
+    const bool fz = c.bf && xattn_supported(dh, N) && !(dh == 256 && g_bf16_variant == 23);
     MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.sd_q, l.sd_q_b, D, fz ? nullptr : w.t1,
                    fz ? (uint16_t*)w.t1 : nullptr, o));
   }
-  if (c.bf && xattn_supported(dh, N)) {
+  if (c.bf && xattn_supported(dh, N) && !(dh == 256 && g_bf16_variant == 23)) {
     MDM_TRY(sd_attn(w.t1, c.h16, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.h16, c.s));  // scores, softmax, PV fused
   } else {
     {

@@ -31,12 +31,12 @@ __device__ __forceinline__ float quad_max(float v) {
   return v;
 }
 // row (t0 + lane&15) of a (M, D) fp32 / bf16 matrix, head h: x[32] at k = 32*ks + 8*q + j
-template <typename HT, bool IN16>
-__device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t row, int D, int h, int q, float (&x)[32]) {
+template <typename HT, bool IN16, int DHT = DH>
+__device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t row, int D, int h, int q, float (&x)[DHT / 4]) {
   if constexpr (IN16) {
-    const uint16_t* p = (const uint16_t*)base + row * D + h * DH + 8 * q;
+    const uint16_t* p = (const uint16_t*)base + row * D + h * DHT + 8 * q;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < DHT / 32; ++ks) {
       const uint4 u = *(const uint4*)(p + 32 * ks);
       x[8 * ks + 0] = HT::lo(u.x), x[8 * ks + 1] = HT::hi(u.x);
       x[8 * ks + 2] = HT::lo(u.y), x[8 * ks + 3] = HT::hi(u.y);
@@ -44,9 +44,9 @@ __device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t 
       x[8 * ks + 6] = HT::lo(u.w), x[8 * ks + 7] = HT::hi(u.w);
     }
   } else {
-    const float* p = (const float*)base + row * D + h * DH + 8 * q;
+    const float* p = (const float*)base + row * D + h * DHT + 8 * q;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < DHT / 32; ++ks) {
       const f32x4 a = *(const f32x4*)(p + 32 * ks), c = *(const f32x4*)(p + 32 * ks + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[8 * ks + j] = a[j], x[8 * ks + 4 + j] = c[j];
@@ -54,13 +54,15 @@ __device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t 
   }
 }
 
-template <typename HT, int NT32, bool IN16>  // ceil(N / 32); q stored as 16-bit or fp32
+template <typename HT, int NT32, bool IN16, int DHT>  // ceil(N / 32); q stored as 16-bit or fp32; head_dim 128 or 256
 __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ qm, const float* __restrict__ kc,
                                                       const float* __restrict__ vc, int S, int H, int N,
                                                       uint16_t* __restrict__ out16, float* __restrict__ out32) {
   typedef typename HT::frag_t frag_t;
-  __shared__ __attribute__((aligned(16))) uint16_t kL[NT32 * 32 * PS];  // k [n][d]
-  __shared__ __attribute__((aligned(16))) uint16_t vT[DH * NS];         // v^T [d][n]
+  constexpr int DH = DHT, PS = DHT + 8;  // (shadow the file-level head_dim-128 constants)
+  extern __shared__ __attribute__((aligned(16))) uint16_t sd_smem[];
+  uint16_t* kL = sd_smem;                 // k [n][d], NT32 * 32 rows of PS
+  uint16_t* vT = sd_smem + NT32 * 32 * PS;  // v^T [d][n], DH rows of NS
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
   for (int i = tid; i < NT32 * 32 * (DH / 4); i += XNT) {
@@ -78,16 +80,16 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
   const int ntile = (S + 15) >> 4;
   for (int tile = wid; tile < ntile; tile += XNT / 64) {
     const int t = tile * 16 + r16, tc = t < S ? t : S - 1;
-    float x[32];
-    load_row<HT, IN16>(qm, (int64_t)b * S + tc, D, h, q, x);
-    frag_t qf[4];
+    float x[DH / 4];
+    load_row<HT, IN16, DHT>(qm, (int64_t)b * S + tc, D, h, q, x);
+    frag_t qf[DH / 32];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag<HT>(x + 8 * ks);
+    for (int ks = 0; ks < DH / 32; ++ks) qf[ks] = make_frag<HT>(x + 8 * ks);
     f32x4 sc[2 * NT32];
 #pragma unroll
     for (int nt = 0; nt < 2 * NT32; ++nt) sc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < DH / 32; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 2 * NT32; ++nt) {
         const frag_t kf = *(const frag_t*)(kL + (16 * nt + r16) * PS + 32 * ks + 8 * q);
@@ -112,9 +114,9 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
         sum += sc[nt][r];
       }
     const float inv = 1.f / quad_sum(sum);
-    f32x4 o[8];
+    f32x4 o[DH / 16];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DH / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NT32; ++s) {
       const u32x4 ub = {HT::pack(sc[2 * s][0] * inv, sc[2 * s][1] * inv), HT::pack(sc[2 * s][2] * inv, sc[2 * s][3] * inv),
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
                         HT::pack(sc[2 * s + 1][2] * inv, sc[2 * s + 1][3] * inv)};
       const frag_t pf = __builtin_bit_cast(frag_t, ub);
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
+      for (int dt = 0; dt < DH / 16; ++dt) {
         const uint2 lo = *(const uint2*)(vT + (16 * dt + r16) * NS + 32 * s + 4 * q);
         const uint2 hi = *(const uint2*)(vT + (16 * dt + r16) * NS + 32 * s + 16 + 4 * q);
         const u32x4 ua = {lo.x, lo.y, hi.x, hi.y};
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
     if (t < S) {
       const int64_t off = ((int64_t)b * S + t) * D + h * DH;
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
+      for (int dt = 0; dt < DH / 16; ++dt) {
         if (out16) *(uint2*)(out16 + off + 16 * dt + 4 * q) = make_uint2(HT::pack(o[dt][0], o[dt][1]), HT::pack(o[dt][2], o[dt][3]));
         if (out32) *(f32x4*)(out32 + off + 16 * dt + 4 * q) = o[dt];
       }
@@ -278,9 +280,24 @@ __global__ __launch_bounds__(XNT, 2) void lin_xattn256_kernel(const void* __rest
   }
 }
 
+template <typename HT, int NT32, bool IN16, int DHT>
+int launch_sd(const void* q, const float* kc, const float* vc, int B, int S, int H, int N, uint16_t* out16, float* out32,
+              hipStream_t s) {
+  constexpr int smem = (NT32 * 32 * (DHT + 8) + DHT * NS) * 2;
+  static bool attr = false;
+  if (smem > 65536 && !attr) {
+    if (hipFuncSetAttribute((const void*)sd_attn_kernel<HT, NT32, IN16, DHT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return MDM_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((sd_attn_kernel<HT, NT32, IN16, DHT>), dim3(B * H), dim3(XNT), smem, s, q, kc, vc, S, H, N, out16, out32);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
 }  // namespace
 
-bool xattn_supported(int dh, int N) { return dh == DH && N >= 1 && N <= NP; }
+bool xattn_supported(int dh, int N) { return (dh == DH || dh == DH2) && N >= 1 && N <= NP; }
 bool lin_xattn_supported(int dh) { return dh == DH || dh == DH2; }
 
 // q_fmt: 0 = fp32 q rows, 1 / 2 = bf16 / fp16 rows; h16: operand format of the MFMAs and of out16 (MDM_H16_*)
@@ -290,25 +307,15 @@ int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, i
   if (q_fmt && q_fmt != h16) return MDM_ERR_ARG;
   if (!xattn_supported(dh, N)) return MDM_ERR_UNSUPPORTED;
   if (!q || !kc || !vc || (!out16 && !out32)) return MDM_ERR_ARG;
-  const dim3 grid(B * H), block(XNT);
-#define MDM_SD(NT, I16)                                                                                              \
-  do {                                                                                                               \
-    if (h16 == MDM_H16_F16) {                                                                                        \
-      hipLaunchKernelGGL((sd_attn_kernel<HF, NT, I16>), grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);        \
-    } else {                                                                                                         \
-      hipLaunchKernelGGL((sd_attn_kernel<HB, NT, I16>), grid, block, 0, s, q, kc, vc, S, H, N, out16, out32);        \
-    }                                                                                                                \
-  } while (0)
-  if (N <= 32) {
-    if (q_bf16) MDM_SD(1, true); else MDM_SD(1, false);
-  } else if (N <= 64) {
-    if (q_bf16) MDM_SD(2, true); else MDM_SD(2, false);
-  } else {
-    if (q_bf16) MDM_SD(3, true); else MDM_SD(3, false);
-  }
+  const bool f16 = h16 == MDM_H16_F16;
+#define MDM_SD(NT, DHT)                                                                                                     \
+  (f16 ? (q_bf16 ? launch_sd<HF, NT, true, DHT>(q, kc, vc, B, S, H, N, out16, out32, s)                                     \
+                 : launch_sd<HF, NT, false, DHT>(q, kc, vc, B, S, H, N, out16, out32, s))                                   \
+       : (q_bf16 ? launch_sd<HB, NT, true, DHT>(q, kc, vc, B, S, H, N, out16, out32, s)                                     \
+                 : launch_sd<HB, NT, false, DHT>(q, kc, vc, B, S, H, N, out16, out32, s)))
+  if (dh == DH2) return N <= 32 ? MDM_SD(1, 256) : (N <= 64 ? MDM_SD(2, 256) : MDM_SD(3, 256));
+  return N <= 32 ? MDM_SD(1, 128) : (N <= 64 ? MDM_SD(2, 128) : MDM_SD(3, 128));
 #undef MDM_SD
-  MDM_RETURN_IF_LAUNCH_FAILED();
-  return MDM_OK;
 }
 
 int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,

@@ -266,3 +266,28 @@ def test_big_width_linear_cross_attention_fused_core(S, N, precision, tol):
     e_f, e_c = rel_inf(fused, ref), rel_inf(chain, ref)
     print(f"big linear cross-attention S={S} N={N} precision {precision}: fused {e_f:.2e}, GEMM-composed {e_c:.2e}")
     assert e_f < tol and not torch.equal(fused, chain)
+
+    # MemoryEfficientCrossAttentionBlock (fast_attention.py:301-330) on the same inputs: the fused scores / softmax / PV core
+    # of csrc/xattn.hip at head_dim 256 (sd_attn_kernel<.., 256>) against the oracle and the GEMM-composed path
+    def run_sd():
+        out = torch.empty_like(hd)
+        L.check(lib.mdm_block_forward(C.byref(pm.model), C.c_int32(0), C.c_int32(L.BLOCK_SDCROSS), C.byref(tcache["tc"]),
+                                      C.c_void_p(hd.data_ptr()), C.c_void_p(scd.data_ptr()), C.c_void_p(ld.data_ptr()),
+                                      C.c_int32(B), C.c_int32(S), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                      C.c_int64(ws.numel()), C.c_void_p(0), C.c_int32(precision), C.c_void_p(L.stream_ptr())))
+        return out.cpu()
+
+    fused = run_sd()
+    lib.mdm_set_gemm_variant(23)
+    try:
+        chain = run_sd()
+    finally:
+        lib.mdm_set_gemm_variant(0)
+    with torch.no_grad():
+        ref = R.softmax_cross_ffn(h, xf, sd, pre + ".sd_cross_attn", H)
+    e_f, e_c = rel_inf(fused, ref), rel_inf(chain, ref)
+    print(f"big softmax cross-attention + FFN S={S} N={N} precision {precision}: fused core {e_f:.2e}, GEMM-composed {e_c:.2e}")
+    assert e_f < tol
+    # in the bf16 mode the GEMM-composed path rounds the same operands to bf16 and accumulates in the same MFMA order: the two
+    # paths may agree bit for bit; in the fp16 mode the composed path still rounds to bf16 and must differ
+    assert precision == 1 or not torch.equal(fused, chain)
