@@ -431,7 +431,9 @@ def main():
             # the contract's roofline entry: the dominant kernel (26 % of the step, profiles/r01_kernel_stats.txt), live
             pmc_k = None
             if traffic is not None:
-                pk = json.load(open(pmc))["per_kernel_MB_per_call"].get("fused_mlp_kernel")
+                per = json.load(open(pmc))["per_kernel_MB_per_call"]
+                per = per.items() if isinstance(per, dict) else per
+                pk = next((v for k, v in per if str(k).startswith("fused_mlp_kernel")), None)
                 pmc_k = (pk["fetch_x2"] + pk["write"]) * 1e6 if pk else None
             rf = line["roofline"]
             rf.update({"achieved": round(live[1] / live[0] / 1e12, 2), "frac": round(live[1] / live[0] / PEAK[a.precision], 4),
