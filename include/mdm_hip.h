@@ -332,8 +332,10 @@ int mdm_motion_postprocess(const float* motion, const int32_t* length, const flo
  * MoEMultiBranchFFN.forward (multi_branch.py:52-61) with both SwitchMoELayers (switch_moe.py:44-111) and the StylizationBlock
  * (stylization.py:20-31) in training mode, and its backward: what loss.backward() does for this block inside
  * DDPMTrainer.update (ddpm_trainer.py:228-244).  fp32 master parameters in the state_dict layouts, the two branches stacked on
- * a leading dimension; the same struct holds the gradients (same shapes, OVERWRITTEN by the backward).  Dropout is taken at
- * p = 0.  The GEMMs are the bf16x3 (fp32-grade) kernel; gradients match fp32 autograd to ~1e-4 relative. */
+ * a leading dimension; the same struct holds the gradients (same shapes, OVERWRITTEN by the backward).  Dropout
+ * (multi_branch.py:57 on each branch's output, stylization.py:16 after the SiLU): dropout_p in [0, 1), masks from the
+ * counter-based generator keyed on (seed, site, row, element), regenerated by the backward (pass the same p and seed);
+ * p > 0 needs D in {256, 512, 1024}.  The GEMMs are the bf16x3 (fp32-grade) kernel; gradients match fp32 autograd to ~1e-5. */
 typedef struct MdmMoeTensors {
   float* ln_w;      /* [2][D]        branches.{b}.layernorm.weight */
   float* ln_b;      /* [2][D] */
@@ -358,12 +360,14 @@ int64_t mdm_moe_train_workspace_bytes(int32_t B, int32_t S, int32_t D, int32_t F
  * the top-2 decisions, int32 [2][B*S][2].  Activations needed by the backward stay in ws. */
 int mdm_moe_ffn_train_forward(const MdmMoeTensors* params, int32_t D, int32_t F, int32_t E, int32_t Te, int32_t De,
                               const float* eph_w, const float* eph_b, const float* x, const float* emb, int32_t B, int32_t S,
-                              float* out, float* lb_loss, int32_t* route_out, void* ws, int64_t ws_bytes, void* stream);
+                              float dropout_p, uint64_t seed, float* out, float* lb_loss, int32_t* route_out, void* ws,
+                              int64_t ws_bytes, void* stream);
 /* given dout = dL/dout [B*S, D] and the workspace of the matching forward: dx [B*S, D], demb [B, De] (optional) and every
  * parameter gradient in `grads`. */
 int mdm_moe_ffn_train_backward(const MdmMoeTensors* params, int32_t D, int32_t F, int32_t E, int32_t Te, int32_t De,
-                               const float* eph_w, const float* x, const float* emb, int32_t B, int32_t S, const float* dout,
-                               float* dx, float* demb, const MdmMoeTensors* grads, void* ws, int64_t ws_bytes, void* stream);
+                               const float* eph_w, const float* x, const float* emb, int32_t B, int32_t S, float dropout_p,
+                               uint64_t seed, const float* dout, float* dx, float* demb, const MdmMoeTensors* grads, void* ws,
+                               int64_t ws_bytes, void* stream);
 /* optimizer plumbing of ddpm_trainer.py:228-244 on flat fp32 buffers: squared gradient norm (device scalar, for
  * clip_grad_norm_) and one Adam step with the clip factor min(1, max_norm / (sqrt(*sumsq) + 1e-6)) folded in (sumsq NULL or
  * max_norm <= 0: no clip). */

@@ -12,10 +12,14 @@
 //                                                                  range comes from the routing offsets (MdmGemmDesc.kgoff)
 // so the expert weight gradients are 2E-batched MFMA GEMMs over exactly the routed rows of each expert, with no host sync.
 // Row-wise backward kernels (one wave per row) cover LayerNorm, the stylization gate, softmax/top-2 and the gathers; column
-// sums (biases, LayerNorm gains, per-sample scale/shift) are accumulated with float atomics.  Dropout (multi_branch.py:57,
-// stylization.py:16) is taken at p = 0: the step is deterministic up to the atomics' summation order.
+// sums (biases, LayerNorm gains, per-sample scale/shift) are accumulated with float atomics.  Dropout (multi_branch.py:57 on
+// each branch's output, stylization.py:16 after the SiLU) uses counter-based masks: element (row, col) of site s keeps its
+// value when the top 24 bits of word col % 4 of Philox4x32-10(counter = (col / 4, row, 0, s), key = seed) are >= p * 2^24, and is
+// scaled by 1 / (1 - p) -- recomputed in the backward, never stored; p = 0 skips the generator.  The step is deterministic up
+// to the atomics' summation order.
 #include "gemm.h"
 #include "kernels.h"
+#include "philox.h"
 #include "row.h"
 
 #define MDM_TRY(expr)                \
@@ -43,6 +47,63 @@ __device__ __forceinline__ float gelu_grad(float x) {
 __device__ __forceinline__ float silu_grad(float z) {
   const float sg = 1.f / (1.f + expf(-z));
   return sg * (1.f + z * (1.f - sg));
+}
+
+// dropout masks for the row image of a wave: m.e[j] = 1 / (1 - p) where the element is kept, 0 where it is dropped
+struct Drop {
+  uint32_t thr;  // p * 2^24 (0 = no dropout)
+  float keep;    // 1 / (1 - p)
+  uint32_t k0, k1;
+};
+template <int NE, bool VEC>
+__device__ __forceinline__ void drop_mask(const Drop& d, int site, int64_t row, int lane, Row<NE, VEC>& m) {
+  static_assert(VEC, "dropout masks are generated per float4 chunk");
+#pragma unroll
+  for (int c = 0; c < NE / 4; ++c) {
+    uint32_t ctr[4] = {(uint32_t)(lane + 64 * c), (uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)site};
+    philox4x32_10(ctr, d.k0, d.k1);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) m.e[4 * c + w] = (ctr[w] >> 8) >= d.thr ? d.keep : 0.f;
+  }
+}
+enum { DROP_BRANCH0 = 0, DROP_BRANCH1 = 1, DROP_STYLE = 2 };
+
+// training-mode stylization input (style_in_kernel with the two dropout sites): a = 0.5 * sum_b drop_b(y2[b,0] + y2[b,1]),
+// s = drop_s(SiLU(LN(a) (1 + scale) + shift))
+template <int NE, bool VEC>
+__global__ __launch_bounds__(256) void style_fwd_train_kernel(const float* __restrict__ y2, const int* __restrict__ pos4,
+                                                              const float* __restrict__ sc, const float* __restrict__ nw,
+                                                              const float* __restrict__ nb, int64_t M, int D, int S, Drop dr,
+                                                              float* __restrict__ sact) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
+    Row<NE, VEC> a, b, c, d, m0, m1, ms;
+    a.load(y2 + (int64_t)pos4[row * 4 + 0] * D, D, lane);
+    b.load(y2 + (int64_t)pos4[row * 4 + 1] * D, D, lane);
+    c.load(y2 + (int64_t)pos4[row * 4 + 2] * D, D, lane);
+    d.load(y2 + (int64_t)pos4[row * 4 + 3] * D, D, lane);
+    if constexpr (VEC) {
+      drop_mask(dr, DROP_BRANCH0, row, lane, m0);
+      drop_mask(dr, DROP_BRANCH1, row, lane, m1);
+      drop_mask(dr, DROP_STYLE, row, lane, ms);
+    } else {  // (the host only launches this kernel at the vectorised widths)
+#pragma unroll
+      for (int j = 0; j < NE; ++j) m0.e[j] = m1.e[j] = ms.e[j] = 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) a.e[j] = ((a.e[j] + b.e[j]) * m0.e[j] + (c.e[j] + d.e[j]) * m1.e[j]) * 0.5f;
+    a.layernorm(nw, nb, D, lane);
+    const float* scb = sc + (row / S) * 2 * (int64_t)D;
+    Row<NE, VEC> scale, shift;
+    scale.load(scb, D, lane);
+    shift.load(scb + D, D, lane);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const float z = a.e[j] * (1.f + scale.e[j]) + shift.e[j];
+      a.e[j] = z / (1.f + expf(-z)) * ms.e[j];
+    }
+    a.store(sact + row * D, D, lane);
+  }
 }
 
 // op 0: y = gelu(x); 1: y *= gelu'(x); 2: y = silu(x); 3: y *= silu'(x)
@@ -75,7 +136,7 @@ template <int NE, bool VEC>
 __global__ __launch_bounds__(256) void style_bwd_kernel(const float* __restrict__ y2, const int* __restrict__ pos4,
                                                         const float* ds, const float* __restrict__ sc,
                                                         const float* __restrict__ nw, const float* __restrict__ nb, int64_t M,
-                                                        int D, int S, float* __restrict__ dzz, float* da_half,
+                                                        int D, int S, Drop dr, float* __restrict__ dzz, float* da_half,
                                                         float* __restrict__ g_nw, float* __restrict__ g_nb) {
   const int lane = threadIdx.x & 63;
   float gw[NE], gb[NE];
@@ -95,6 +156,20 @@ __global__ __launch_bounds__(256) void style_bwd_kernel(const float* __restrict_
     Row<NE, VEC> scale, shift;
     scale.load(scb, D, lane);
     shift.load(scb + D, D, lane);
+    if constexpr (VEC) {
+      if (dr.thr) {  // the forward's masks, regenerated: branch outputs and the incoming gradient (taken after the SiLU dropout)
+        Row<NE, VEC> m0, m1, ms;
+        drop_mask(dr, DROP_BRANCH0, row, lane, m0);
+        drop_mask(dr, DROP_BRANCH1, row, lane, m1);
+        drop_mask(dr, DROP_STYLE, row, lane, ms);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          a.e[j] = (a.e[j] + b.e[j]) * m0.e[j], b.e[j] = 0.f;
+          c.e[j] = (c.e[j] + d.e[j]) * m1.e[j], d.e[j] = 0.f;
+          g.e[j] *= ms.e[j];
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NE; ++j) a.e[j] = ((a.e[j] + b.e[j]) + (c.e[j] + d.e[j])) * 0.5f;
     const float mean = a.sum() / D;
@@ -140,7 +215,7 @@ __global__ __launch_bounds__(256) void style_bwd_kernel(const float* __restrict_
 template <int NE, bool VEC>
 __global__ __launch_bounds__(256) void routed_bwd_kernel(const float* __restrict__ da_half, const float* __restrict__ y2,
                                                          const int* __restrict__ perm, const float* __restrict__ rowscale,
-                                                         int64_t M, int64_t rows, int D, float* __restrict__ dy,
+                                                         int64_t M, int64_t rows, int D, Drop dr, float* __restrict__ dy,
                                                          float* __restrict__ dp) {
   const int lane = threadIdx.x & 63;
   for (int64_t r = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * WPB) {
@@ -149,6 +224,14 @@ __global__ __launch_bounds__(256) void routed_bwd_kernel(const float* __restrict
     Row<NE, VEC> d, y;
     d.load(da_half + tok * D, D, lane);
     y.load(y2 + r * D, D, lane);
+    if constexpr (VEC) {
+      if (dr.thr) {  // this branch's output dropout (multi_branch.py:57): the gradient passes through the same mask
+        Row<NE, VEC> mb;
+        drop_mask(dr, perm[r] >= M ? DROP_BRANCH1 : DROP_BRANCH0, tok, lane, mb);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) d.e[j] *= mb.e[j];
+      }
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
@@ -368,6 +451,16 @@ bool shape_ok(int B, int S, int D, int F, int E, int Te, int De) {
 
 GemmArgs x3() { return gemm_defaults(3); }
 
+// p in [0, 1): threshold on the top 24 random bits; dropout needs the vectorised row widths
+bool make_drop(float p, uint64_t seed, int D, Drop& d) {
+  d.thr = 0, d.keep = 1.f, d.k0 = (uint32_t)seed, d.k1 = (uint32_t)(seed >> 32);
+  if (p == 0.f) return true;
+  if (!(p > 0.f && p < 1.f) || (D != 256 && D != 512 && D != 1024)) return false;
+  d.thr = (uint32_t)(p * 16777216.0f);
+  d.keep = 16777216.0f / (16777216.0f - (float)d.thr);  // exactly 1 / P(keep)
+  return true;
+}
+
 #define ROWK(KERNEL, grid, ...)                                                              \
   do {                                                                                       \
     if (D == 512) {                                         \
@@ -409,10 +502,12 @@ extern "C" int64_t mdm_moe_train_workspace_bytes(int32_t B, int32_t S, int32_t D
 // forward in training mode: saves LN outputs, routing, gathered expert inputs, pre-activations, hidden and routed outputs
 extern "C" int mdm_moe_ffn_train_forward(const MdmMoeTensors* P, int32_t D, int32_t F, int32_t E, int32_t Te, int32_t De,
                                          const float* eph_w, const float* eph_b, const float* x, const float* emb, int32_t B,
-                                         int32_t S, float* out, float* lb_loss, int32_t* route_out, void* ws, int64_t ws_bytes,
-                                         void* stream) {
+                                         int32_t S, float dropout_p, uint64_t seed, float* out, float* lb_loss,
+                                         int32_t* route_out, void* ws, int64_t ws_bytes, void* stream) {
   if (!P || !x || !emb || !out || !ws || !shape_ok(B, S, D, F, E, Te, De)) return MDM_ERR_ARG;
   if (De != Te && (!eph_w || !eph_b)) return MDM_ERR_ARG;
+  Drop dr;
+  if (!make_drop(dropout_p, seed, D, dr)) return dropout_p >= 0.f && dropout_p < 1.f ? MDM_ERR_UNSUPPORTED : MDM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const TrainWork w = carve_train(B, S, D, F, E, Te, ws);
   if (ws_bytes < w.bytes) return MDM_ERR_ARG;
@@ -459,7 +554,12 @@ extern "C" int mdm_moe_ffn_train_forward(const MdmMoeTensors* P, int32_t D, int3
     g.bias = P->st_emb_b, g.C = w.sc, g.ldc = 2 * D;
     MDM_TRY(gemm(g, s));
   }
-  MDM_TRY(style_in(w.y2, M, D, S, nullptr, nullptr, P->st_norm_w, P->st_norm_b, w.sc, w.pos4, 0, w.sact, 0, s));
+  if (dr.thr) {
+    ROWK(style_fwd_train_kernel, row_grid(M), (const float*)w.y2, (const int*)w.pos4, (const float*)w.sc, (const float*)P->st_norm_w,
+         (const float*)P->st_norm_b, M, (int)D, (int)S, dr, w.sact);
+  } else {
+    MDM_TRY(style_in(w.y2, M, D, S, nullptr, nullptr, P->st_norm_w, P->st_norm_b, w.sc, w.pos4, 0, w.sact, 0, s));
+  }
   {
     GemmArgs g = x3();  // out = x + SiLU(...) Wo^T + bo               (stylization.py:29, multi_branch.py:60)
     g.A = op_f32(w.sact, D), g.W = op_f32(P->st_out_w, D), g.M = (int)M, g.N = D, g.K = D;
@@ -474,10 +574,12 @@ extern "C" int mdm_moe_ffn_train_forward(const MdmMoeTensors* P, int32_t D, int3
 // backward: consumes the workspace of the matching forward.  G = every gradient tensor (overwritten); dx, demb optional
 extern "C" int mdm_moe_ffn_train_backward(const MdmMoeTensors* P, int32_t D, int32_t F, int32_t E, int32_t Te, int32_t De,
                                           const float* eph_w, const float* x, const float* emb, int32_t B, int32_t S,
-                                          const float* dout, float* dx, float* demb, const MdmMoeTensors* G, void* ws,
-                                          int64_t ws_bytes, void* stream) {
+                                          float dropout_p, uint64_t seed, const float* dout, float* dx, float* demb,
+                                          const MdmMoeTensors* G, void* ws, int64_t ws_bytes, void* stream) {
   if (!P || !G || !x || !emb || !dout || !dx || !ws || !shape_ok(B, S, D, F, E, Te, De)) return MDM_ERR_ARG;
   if (De != Te && !eph_w) return MDM_ERR_ARG;
+  Drop dr;
+  if (!make_drop(dropout_p, seed, D, dr)) return dropout_p >= 0.f && dropout_p < 1.f ? MDM_ERR_UNSUPPORTED : MDM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const TrainWork w = carve_train(B, S, D, F, E, Te, ws);
   if (ws_bytes < w.bytes) return MDM_ERR_ARG;
@@ -505,7 +607,7 @@ extern "C" int mdm_moe_ffn_train_backward(const MdmMoeTensors* P, int32_t D, int
   }
   MDM_TRY(colsum(dout, D, M, D, nullptr, 0, 0, G->st_out_b, s));
   ROWK(style_bwd_kernel, row_grid(M), (const float*)w.y2, (const int*)w.pos4, (const float*)w.ds, (const float*)w.sc,
-       (const float*)P->st_norm_w, (const float*)P->st_norm_b, M, (int)D, (int)S, w.dzz, w.ds, G->st_norm_w, G->st_norm_b);
+       (const float*)P->st_norm_w, (const float*)P->st_norm_b, M, (int)D, (int)S, dr, w.dzz, w.ds, G->st_norm_w, G->st_norm_b);
   MDM_TRY(colsum(w.dzz, 2 * D, M, 2 * D, nullptr, 0, S, w.demb_out, s));  // per-sample d(scale | shift)
   {
     GemmArgs g = x3();  // dWe = d(scale|shift)^T SiLU(emb)
@@ -529,7 +631,7 @@ extern "C" int mdm_moe_ffn_train_backward(const MdmMoeTensors* P, int32_t D, int
   }
   // ---- experts ------------------------------------------------------------------------------------------------------------
   ROWK(routed_bwd_kernel, row_grid(4 * M), (const float*)w.ds, (const float*)w.y2, (const int*)w.perm, (const float*)w.rowscale, M,
-       4 * M, (int)D, w.dy, w.dp);
+       4 * M, (int)D, dr, w.dy, w.dp);
   {
     GemmArgs g = x3();  // dW2[g] = dy_g^T hid_g over the routed rows of group g
     g.A = op_f32_kstride(w.dy, D), g.W = op_f32_kstride(w.hid, F), g.M = D, g.N = F, g.K = (int)(4 * M);

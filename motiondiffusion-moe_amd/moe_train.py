@@ -11,8 +11,10 @@ Mirrors what the reference does for this block inside a training iteration:
     block's flat gradient buffer (RCCL over xGMI; `gloo` in the CPU tests of the host logic).
 
 Parameters, gradients and the Adam moments live in three flat fp32 device buffers; the per-tensor views follow the
-reference's state_dict layouts with the two branches (and the experts) stacked on leading dimensions.  Dropout is taken at
-p = 0.  There is no CPU fallback: without the HIP library every call raises.
+reference's state_dict layouts with the two branches (and the experts) stacked on leading dimensions.  Dropout
+(multi_branch.py:57, stylization.py:16) uses counter-based masks keyed on (seed, site, row, element): ``dropout=p`` with a
+fresh ``seed`` per iteration (the trainer advances it itself) reproduces a training-mode forward; ``dropout=0`` is eval
+behaviour.  There is no CPU fallback: without the HIP library every call raises.
 """
 import ctypes as C
 import math
@@ -61,8 +63,9 @@ class MoEFFNTrainer:
     """One ``MoEMultiBranchFFN`` (latent D, expert hidden F, E experts, time-embedding width Te) in training mode."""
 
     def __init__(self, D: int, F: int, E: int, Te: int, device="cuda", lr: float = 2e-4, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8, max_norm: float = 1.0):
+                 eps: float = 1e-8, max_norm: float = 1.0, dropout: float = 0.0, seed: int = 0):
         self.D, self.F, self.E, self.Te = D, F, E, Te
+        self.dropout, self.seed = float(dropout), int(seed)  # the mask of iteration i uses seed + i (see forward)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.MdmError("the MoE training step runs on the HIP path only (no CPU fallback)")
@@ -125,20 +128,22 @@ class MoEFFNTrainer:
             L.require_cuda(ew, eb)
         ws = self._workspace(B, S)
         out = torch.empty_like(x)
+        mask_seed = (self.seed + self.step_count) & 0xFFFFFFFFFFFFFFFF  # one mask per optimizer iteration
         with torch.cuda.device(self.device):
             L.check(L.lib().mdm_moe_ffn_train_forward(
                 C.byref(self.params.struct), self.D, self.F, self.E, self.Te, De, C.c_void_p(L.ptr(ew)), C.c_void_p(L.ptr(eb)),
-                C.c_void_p(x.data_ptr()), C.c_void_p(emb.data_ptr()), B, S, C.c_void_p(out.data_ptr()),
+                C.c_void_p(x.data_ptr()), C.c_void_p(emb.data_ptr()), B, S, C.c_float(self.dropout), C.c_uint64(mask_seed),
+                C.c_void_p(out.data_ptr()),
                 C.c_void_p(self.lb_loss.data_ptr()), C.c_void_p(L.ptr(route_out)), C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()),
                 C.c_void_p(L.stream_ptr())), "mdm_moe_ffn_train_forward")
-        self._saved = (x, emb, ew, B, S, De)
+        self._saved = (x, emb, ew, B, S, De, mask_seed)
         return out
 
     def backward(self, dout: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """dL/dout (B, S, D) -> (dL/dx, dL/demb); parameter gradients land in self.grads (overwritten)."""
         if self._saved is None:
             raise L.MdmError("backward() without a forward()")
-        x, emb, ew, B, S, De = self._saved
+        x, emb, ew, B, S, De, mask_seed = self._saved
         L.require_cuda(dout)
         dout = dout.contiguous().float()
         if tuple(dout.shape) != (B, S, self.D):
@@ -147,7 +152,8 @@ class MoEFFNTrainer:
         with torch.cuda.device(self.device):
             L.check(L.lib().mdm_moe_ffn_train_backward(
                 C.byref(self.params.struct), self.D, self.F, self.E, self.Te, De, C.c_void_p(L.ptr(ew)), C.c_void_p(x.data_ptr()),
-                C.c_void_p(emb.data_ptr()), B, S, C.c_void_p(dout.data_ptr()), C.c_void_p(dx.data_ptr()),
+                C.c_void_p(emb.data_ptr()), B, S, C.c_float(self.dropout), C.c_uint64(mask_seed), C.c_void_p(dout.data_ptr()),
+                C.c_void_p(dx.data_ptr()),
                 C.c_void_p(demb.data_ptr()), C.byref(self.grads.struct), C.c_void_p(self._ws.data_ptr()),
                 C.c_int64(self._ws.numel()), C.c_void_p(L.stream_ptr())), "mdm_moe_ffn_train_backward")
         self._saved = None

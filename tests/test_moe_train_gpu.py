@@ -77,6 +77,35 @@ def test_block_gradients_match_autograd(D, F, E, Te, De, B, S):
     assert max(errs.values()) < 2e-3, errs
 
 
+@pytest.mark.parametrize("D,F,E,Te,De,B,S,p", [(256, 320, 4, 128, 256, 2, 19, 0.1), (512, 1024, 8, 2048, 512, 2, 24, 0.1), (256, 128, 3, 96, 64, 1, 9, 0.5)])
+def test_training_mode_dropout_matches_the_oracle_with_the_same_masks(D, F, E, Te, De, B, S, p):
+    """Dropout on each branch's output (multi_branch.py:57) and after the SiLU of the stylization block (stylization.py:16):
+    the counter-based masks are restated in numpy (oracle/moe_train_ref.dropout_masks) and applied to the oracle's forward;
+    outputs and every gradient must then agree as in eval mode, and the fraction of dropped elements must be p."""
+    sd = _make_sd(D, F, E, Te, seed=D + E + 1)
+    x, emb, eph, dout = _inputs(B, S, D, De, Te, seed=S + 1)
+    seed = 0x1234567800000007
+    tr = _trainer(D, F, E, Te, sd, dropout=p, seed=seed)
+    out, dx, demb, route, lb = _hip_forward_backward(tr, x, emb, eph, dout)
+    masks = T.dropout_masks(seed, B * S, D, p)
+    frac = float(sum((m == 0).float().mean() for m in masks) / 3)
+    assert abs(frac - p) < 0.03, frac
+    o_out, o_dx, o_demb, o_g, o_lb, trace = T.moe_ffn_grads(sd, PREFIX, E, x, emb, eph, dout, masks=masks)
+    for b in range(2):
+        assert torch.equal(trace[f"{PREFIX}.branches.{b}.top2_idx"], route[b])
+    errs = {"out": rel_inf(out, o_out), "dx": rel_inf(dx, o_dx), "demb": rel_inf(demb, o_demb)}
+    for name, ks in pkg("moe_train").reference_keys(PREFIX, E).items():
+        g = tr.grads.views[name].cpu()
+        errs["d" + name] = rel_inf(g, torch.stack([o_g.get(k, torch.zeros_like(sd[k])) for k in ks]).reshape(g.shape))
+    print(f"training-mode dropout p={p} D={D}: dropped {frac:.3f}; " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) < 2e-3, errs
+    # eval behaviour is a different forward, and a different seed is a different mask
+    tr0 = _trainer(D, F, E, Te, sd)
+    assert rel_inf(tr0.forward(x.cuda(), emb.cuda(), None if eph is None else (eph[0].cuda(), eph[1].cuda())).cpu(), out) > 1e-2
+    with pytest.raises(Exception):
+        pkg("moe_train").MoEFFNTrainer(64, 64, 4, 64, dropout=0.1).forward(torch.zeros(1, 4, 64, device="cuda"), torch.zeros(1, 64, device="cuda"))
+
+
 def test_unused_experts_get_zero_gradients_and_empty_groups_are_safe():
     """E = 16 with 5 tokens: most expert groups are empty (K range of length 0 in the weight-gradient GEMM)."""
     D, F, E, Te = 64, 64, 16, 64
