@@ -139,6 +139,9 @@ __global__ __launch_bounds__(256) void style_bwd_kernel(const float* __restrict_
                                                         int D, int S, Drop dr, float* __restrict__ dzz, float* da_half,
                                                         float* __restrict__ g_nw, float* __restrict__ g_nb) {
   const int lane = threadIdx.x & 63;
+  __shared__ float red[2 * 1024];  // the block's column sums (gain | bias gradients): one global atomic per column and block
+  for (int i = threadIdx.x; i < 2 * D; i += 256) red[i] = 0.f;
+  __syncthreads();
   float gw[NE], gb[NE];
 #pragma unroll
   for (int j = 0; j < NE; ++j) gw[j] = gb[j] = 0.f;
@@ -206,8 +209,10 @@ __global__ __launch_bounds__(256) void style_bwd_kernel(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
     const int col = row_col<NE, VEC>(j, lane);
-    if (col < D) atomicAdd(g_nw + col, gw[j]), atomicAdd(g_nb + col, gb[j]);
+    if (col < D) atomicAdd(red + col, gw[j]), atomicAdd(red + D + col, gb[j]);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) atomicAdd((i < D ? g_nw : g_nb - D) + i, red[i]);
 }
 
 // routed rows: y2[r] = p_r * expert(h)[r] was added to its token's branch output (switch_moe.py:109):
@@ -256,6 +261,12 @@ __global__ __launch_bounds__(256) void gate_ln_bwd_kernel(const float* __restric
                                                           float* __restrict__ dx, float* __restrict__ g_ln_w,
                                                           float* __restrict__ g_ln_b) {
   const int lane = threadIdx.x & 63;
+  extern __shared__ __attribute__((aligned(16))) float gl_smem[];  // gate rows [2][E][D], then the block's column sums [4][D]
+  float* gws = gl_smem;
+  float* red = gl_smem + 2 * E * D;
+  for (int i = threadIdx.x; i < 2 * E * D; i += 256) gws[i] = gate_w[i];
+  for (int i = threadIdx.x; i < 4 * D; i += 256) red[i] = 0.f;
+  __syncthreads();
   float gw[2][NE], gb[2][NE];
 #pragma unroll
   for (int br = 0; br < 2; ++br)
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256) void gate_ln_bwd_kernel(const float* __restric
       b.load(ln_b + br * D, D, lane);
 #pragma unroll
       for (int j = 0; j < NE; ++j) h.e[j] = xh.e[j] * w.e[j] + b.e[j];
-      const float* gwb = gate_w + (int64_t)br * E * D;
+      const float* gwb = gws + br * E * D;
       float logit[16], mx = -3.0e38f;
       for (int e = 0; e < E; ++e) {
         Row<NE, VEC> g;
@@ -335,8 +346,10 @@ __global__ __launch_bounds__(256) void gate_ln_bwd_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
       const int col = row_col<NE, VEC>(j, lane);
-      if (col < D) atomicAdd(g_ln_w + br * D + col, gw[br][j]), atomicAdd(g_ln_b + br * D + col, gb[br][j]);
+      if (col < D) atomicAdd(red + br * D + col, gw[br][j]), atomicAdd(red + (2 + br) * D + col, gb[br][j]);
     }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * D; i += 256) atomicAdd((i < 2 * D ? g_ln_w : g_ln_b - 2 * D) + i, red[i]);
 }
 
 // out[g][c] += sum of X[r][c] over the rows r of group g; groups = row ranges goff[g]..goff[g+1], or uniform group_rows, or
@@ -368,6 +381,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     acc += X[r * ld + c];
   }
   atomicAdd(out + (int64_t)g * C + c, acc);
+}
+
+// K ranges of a split-K weight-gradient GEMM: `reps` consecutive row spaces of `total` rows, each cut into `ns` chunks:
+// out[r * ns + i] = r * total + min(i * chunk, total), out[reps * ns] = reps * total
+__global__ void splitk_offsets_kernel(int* __restrict__ out, int ns, int chunk, int total, int reps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > reps * ns) return;
+  const int r = i / ns, c = i - r * ns;
+  out[i] = i == reps * ns ? reps * total : r * total + (c * chunk < total ? c * chunk : total);
 }
 
 // get_load_balancing_loss (switch_moe.py:113-145) of both SwitchMoE layers from this forward's counters [2][E] each
@@ -413,9 +435,11 @@ inline int ew_grid(int64_t n) {
 struct TrainWork {
   float *hn, *xg, *pre, *hid, *y2, *dy, *sact, *ds, *dzz, *embp, *semb, *sc, *demb_out, *dembp, *dlogits, *dp, *cnt;
   float *top_val, *rowscale, *uimp;
-  int *top_idx, *perm, *pos4, *hist, *goff, *cursor;
+  int *top_idx, *perm, *pos4, *hist, *goff, *cursor, *kso, *ksg;
+  float *part_o, *part_g;  // split-K partials of dWo [NSK][D*D] and dWg [2*NSK][E*D]
   int64_t bytes;
 };
+constexpr int NSK = 32;  // K chunks of the long-K weight gradients (K = B*S rows, outputs of only D x D / E x D)
 
 struct Bump2 {
   uint8_t* base;
@@ -441,6 +465,8 @@ TrainWork carve_train(int B, int S, int D, int F, int E, int Te, void* ws) {
   w.top_val = b.take<float>(4 * M), w.rowscale = b.take<float>(4 * M), w.uimp = b.take<float>(1024 * 64);
   w.top_idx = b.take<int>(4 * M), w.perm = b.take<int>(4 * M), w.pos4 = b.take<int>(4 * M), w.hist = b.take<int>(1024 * 32);
   w.goff = b.take<int>(2 * E + 1), w.cursor = b.take<int>(2 * E);
+  w.kso = b.take<int>(NSK + 1), w.ksg = b.take<int>(2 * NSK + 1);
+  w.part_o = b.take<float>((int64_t)NSK * D * D), w.part_g = b.take<float>((int64_t)2 * NSK * E * D);
   w.bytes = b.off;
   return w;
 }
@@ -475,6 +501,41 @@ bool make_drop(float p, uint64_t seed, int D, Drop& d) {
       hipLaunchKernelGGL((KERNEL<16, false>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);     \
     }                                                                                        \
   } while (0)
+
+// row-wise backward kernels that end in column-sum atomics: few, fat workgroups (every wave walks ~12 rows) so that the
+// atomics per address stay in the hundreds
+inline int acc_grid(int64_t M) {
+  const int g = row_grid(M);
+  return g > 256 ? 256 : g;
+}
+
+template <int NE, bool VEC>
+int launch_gate_ln_one(int D, int E, int grid, hipStream_t s, const float* x, const float* dout, const float* dxg, const float* dp,
+                       const int* pos4, const int* top_idx, const float* ln_w, const float* ln_b, const float* gate_w,
+                       const float* gate_b, int64_t M, float* dlogits, float* dx, float* g_ln_w, float* g_ln_b) {
+  const int smem = (2 * E * D + 4 * D) * 4;
+  static int attr = 0;
+  if (smem > 65536 && smem > attr) {
+    if (hipFuncSetAttribute((const void*)gate_ln_bwd_kernel<NE, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return MDM_ERR_LAUNCH;
+    attr = smem;
+  }
+  hipLaunchKernelGGL((gate_ln_bwd_kernel<NE, VEC>), dim3(grid), dim3(256), smem, s, x, dout, dxg, dp, pos4, top_idx, ln_w, ln_b, gate_w,
+                     gate_b, M, D, E, dlogits, dx, g_ln_w, g_ln_b);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+#define GLB_ARGS D, E, grid, s, x, dout, dxg, dp, pos4, top_idx, ln_w, ln_b, gate_w, gate_b, M, dlogits, dx, g_ln_w, g_ln_b
+int launch_gate_ln_bwd(int D, int E, int grid, hipStream_t s, const float* x, const float* dout, const float* dxg, const float* dp,
+                       const int* pos4, const int* top_idx, const float* ln_w, const float* ln_b, const float* gate_w,
+                       const float* gate_b, int64_t M, float* dlogits, float* dx, float* g_ln_w, float* g_ln_b) {
+  if (D == 512) return launch_gate_ln_one<8, true>(GLB_ARGS);
+  if (D == 1024) return launch_gate_ln_one<16, true>(GLB_ARGS);
+  if (D == 256) return launch_gate_ln_one<4, true>(GLB_ARGS);
+  if (D <= 256) return launch_gate_ln_one<4, false>(GLB_ARGS);
+  return launch_gate_ln_one<16, false>(GLB_ARGS);
+}
+#undef GLB_ARGS
 
 int colsum(const float* X, int64_t ld, int64_t rows, int C, const int* goff, int ngroups, int64_t group_rows, float* out,
            hipStream_t s) {
@@ -600,13 +661,20 @@ extern "C" int mdm_moe_ffn_train_backward(const MdmMoeTensors* P, int32_t D, int
     g.A = op_f32(dout, D), g.W = op_f32_kstride(P->st_out_w, D), g.M = (int)M, g.N = D, g.K = D, g.C = w.ds, g.ldc = D;
     MDM_TRY(gemm(g, s));
   }
+  const int chunk = (int)((M + NSK - 1) / NSK);
   {
-    GemmArgs g = x3();  // dWo = dout^T SiLU(z)
-    g.A = op_f32_kstride(dout, D), g.W = op_f32_kstride(w.sact, D), g.M = D, g.N = D, g.K = (int)M, g.C = G->st_out_w, g.ldc = D;
+    // dWo = dout^T SiLU(z): a D x D output reduced over K = M rows would run on 16 workgroups; split K into NSK chunks (the
+    // per-batch K ranges of the weight-gradient mode), partials summed by the column-sum kernel
+    hipLaunchKernelGGL(splitk_offsets_kernel, dim3(1), dim3(128), 0, s, w.kso, NSK, chunk, (int)M, 1);
+    GemmArgs g = x3();
+    g.A = op_f32_kstride(dout, D), g.W = op_f32_kstride(w.sact, D), g.M = D, g.N = D, g.K = (int)M;
+    g.batch = NSK, g.kgoff = w.kso, g.C = w.part_o, g.ldc = D, g.c_bs1 = (int64_t)D * D;
     MDM_TRY(gemm(g, s));
+    MDM_TRY(zero(G->st_out_w, (int64_t)D * D, s));
+    MDM_TRY(colsum(w.part_o, (int64_t)D * D, NSK, D * D, nullptr, 0, 0, G->st_out_w, s));
   }
   MDM_TRY(colsum(dout, D, M, D, nullptr, 0, 0, G->st_out_b, s));
-  ROWK(style_bwd_kernel, row_grid(M), (const float*)w.y2, (const int*)w.pos4, (const float*)w.ds, (const float*)w.sc,
+  ROWK(style_bwd_kernel, acc_grid(M), (const float*)w.y2, (const int*)w.pos4, (const float*)w.ds, (const float*)w.sc,
        (const float*)P->st_norm_w, (const float*)P->st_norm_b, M, (int)D, (int)S, dr, w.dzz, w.ds, G->st_norm_w, G->st_norm_b);
   MDM_TRY(colsum(w.dzz, 2 * D, M, 2 * D, nullptr, 0, S, w.demb_out, s));  // per-sample d(scale | shift)
   {
@@ -660,14 +728,18 @@ extern "C" int mdm_moe_ffn_train_backward(const MdmMoeTensors* P, int32_t D, int
     MDM_TRY(gemm(g, s));
   }
   // ---- gate + branch LayerNorms ---------------------------------------------------------------------------------------------
-  ROWK(gate_ln_bwd_kernel, row_grid(M), x, dout, (const float*)w.dy, (const float*)w.dp, (const int*)w.pos4, (const int*)w.top_idx,
-       (const float*)P->ln_w, (const float*)P->ln_b, (const float*)P->gate_w, (const float*)P->gate_b, M, (int)D, (int)E, w.dlogits, dx,
-       G->ln_w, G->ln_b);
+  MDM_TRY(launch_gate_ln_bwd(D, E, acc_grid(M), s, x, dout, (const float*)w.dy, (const float*)w.dp, (const int*)w.pos4, (const int*)w.top_idx,
+                             (const float*)P->ln_w, (const float*)P->ln_b, (const float*)P->gate_w, (const float*)P->gate_b, M, w.dlogits,
+                             dx, G->ln_w, G->ln_b));
   {
-    GemmArgs g = x3();  // dWg[b] = dlogits_b^T LN_b(x)
-    g.A = op_f32_kstride(w.dlogits, E), g.A.bs1 = M * E, g.W = op_f32_kstride(w.hn, D), g.W.bs1 = M * D;
-    g.M = E, g.N = D, g.K = (int)M, g.batch = 2, g.C = G->gate_w, g.ldc = D, g.c_bs1 = (int64_t)E * D;
+    // dWg[b] = dlogits_b^T LN_b(x): E x D outputs over K = M rows -> split K; both branches are one [2M]-row space
+    hipLaunchKernelGGL(splitk_offsets_kernel, dim3(1), dim3(128), 0, s, w.ksg, NSK, chunk, (int)M, 2);
+    GemmArgs g = x3();
+    g.A = op_f32_kstride(w.dlogits, E), g.W = op_f32_kstride(w.hn, D);
+    g.M = E, g.N = D, g.K = (int)(2 * M), g.batch = 2 * NSK, g.kgoff = w.ksg, g.C = w.part_g, g.ldc = D, g.c_bs1 = (int64_t)E * D;
     MDM_TRY(gemm(g, s));
+    MDM_TRY(zero(G->gate_w, (int64_t)2 * E * D, s));
+    MDM_TRY(colsum(w.part_g, (int64_t)E * D, 2 * NSK, E * D, nullptr, 0, NSK, G->gate_w, s));
   }
   MDM_TRY(colsum(w.dlogits, E, 2 * M, E, nullptr, 0, M, G->gate_b, s));
   MDM_RETURN_IF_LAUNCH_FAILED();

@@ -6,7 +6,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 mt = importlib.import_module("motiondiffusion-moe_amd.moe_train")
 B, S, D, F, E = [int(a) for a in sys.argv[1:6]] if len(sys.argv) >= 6 else (64, 196, 512, 1024, 8)
 Te = 4 * D
