@@ -129,9 +129,8 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
         const uint2 hi = *(const uint2*)(vT + (16 * dt + r16) * NS + 32 * s + 16 + 4 * q);
         const u32x4 ua = {lo.x, lo.y, hi.x, hi.y};
         o[dt] = HT::mfma16(__builtin_bit_cast(frag_t, ua), pf, o[dt]);  // D[d][t]
-        if constexpr (DH > 128) {  // head_dim 256: keep hipcc from hoisting all NT32 * 16 value-fragment reads (246 spilled VGPRs)
-          if ((dt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+        // keep hipcc from hoisting all NT32 * DH / 16 value-fragment reads (246 spilled VGPRs at head_dim 256, 6 at 128)
+        if ((dt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (t < S) {
