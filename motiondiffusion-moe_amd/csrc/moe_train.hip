@@ -383,6 +383,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   atomicAdd(out + (int64_t)g * C + c, acc);
 }
 
+// fp32 master weights -> bf16 hi / lo planes for the LDS-DMA staged bf16x3 GEMM (gemm3.hip), once per step and orientation:
+// groups of [R][C] matrices, straight ([R][C]: forward Linear) or transposed ([C][R]: the data-gradient GEMM reads W^T rows)
+__global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ src, int R, int C, int transpose,
+                                                          uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+  __shared__ float tile[32][33];
+  const int g = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const float* sg = src + (int64_t)g * R * C;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) tile[i][tx] = (r0 + i < R && c0 + tx < C) ? sg[(int64_t)(r0 + i) * C + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    float v;
+    int64_t o;
+    bool ok;
+    if (transpose) {  // dst[g][c0 + i][r0 + tx]
+      v = tile[tx][i], ok = c0 + i < C && r0 + tx < R, o = (int64_t)g * R * C + (int64_t)(c0 + i) * R + r0 + tx;
+    } else {
+      v = tile[i][tx], ok = r0 + i < R && c0 + tx < C, o = (int64_t)g * R * C + (int64_t)(r0 + i) * C + c0 + tx;
+    }
+    if (ok) {
+      const uint32_t h = pack_bf16(v, 0.f) & 0xffffu;
+      hi[o] = (uint16_t)h;
+      lo[o] = (uint16_t)(pack_bf16(v - bf16_lo_f32(h), 0.f) & 0xffffu);
+    }
+  }
+}
+
 // K ranges of a split-K weight-gradient GEMM: `reps` consecutive row spaces of `total` rows, each cut into `ns` chunks:
 // out[r * ns + i] = r * total + min(i * chunk, total), out[reps * ns] = reps * total
 __global__ void splitk_offsets_kernel(int* __restrict__ out, int ns, int chunk, int total, int reps) {
@@ -437,6 +464,7 @@ struct TrainWork {
   float *top_val, *rowscale, *uimp;
   int *top_idx, *perm, *pos4, *hist, *goff, *cursor, *kso, *ksg;
   float *part_o, *part_g;  // split-K partials of dWo [NSK][D*D] and dWg [2*NSK][E*D]
+  uint16_t* wp[8];         // bf16 hi / lo planes of W1, W2, W1^T, W2^T (packed per step when D and F are multiples of 32)
   int64_t bytes;
 };
 constexpr int NSK = 32;  // K chunks of the long-K weight gradients (K = B*S rows, outputs of only D x D / E x D)
@@ -467,6 +495,7 @@ TrainWork carve_train(int B, int S, int D, int F, int E, int Te, void* ws) {
   w.goff = b.take<int>(2 * E + 1), w.cursor = b.take<int>(2 * E);
   w.kso = b.take<int>(NSK + 1), w.ksg = b.take<int>(2 * NSK + 1);
   w.part_o = b.take<float>((int64_t)NSK * D * D), w.part_g = b.take<float>((int64_t)2 * NSK * E * D);
+  for (int i = 0; i < 8; ++i) w.wp[i] = b.take<uint16_t>((int64_t)2 * E * F * D);
   w.bytes = b.off;
   return w;
 }
@@ -476,6 +505,12 @@ bool shape_ok(int B, int S, int D, int F, int E, int Te, int De) {
 }
 
 GemmArgs x3() { return gemm_defaults(3); }
+inline bool planes_ok(int D, int F) { return (D % 32) == 0 && (F % 32) == 0; }
+int pack_planes(const float* src, int G, int R, int C, bool transpose, uint16_t* hi, uint16_t* lo, hipStream_t s) {
+  hipLaunchKernelGGL(pack_planes_kernel, dim3((C + 31) / 32, (R + 31) / 32, G), dim3(256), 0, s, src, R, C, transpose ? 1 : 0, hi, lo);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
 
 // p in [0, 1): threshold on the top 24 random bits; dropout needs the vectorised row widths
 bool make_drop(float p, uint64_t seed, int D, Drop& d) {
@@ -586,9 +621,16 @@ extern "C" int mdm_moe_ffn_train_forward(const MdmMoeTensors* P, int32_t D, int3
   if (route_out && hipMemcpyAsync(route_out, w.top_idx, 4 * M * sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return MDM_ERR_LAUNCH;
   ROWK(gather_rows_kernel, row_grid(4 * M), (const float*)w.hn, (const int*)w.perm, w.xg, 4 * M, (int)D);
+  const bool planes = planes_ok(D, F);
+  if (planes) {  // this step's weights as bf16 hi / lo planes, both orientations (the backward reads the transposed ones)
+    MDM_TRY(pack_planes(P->w1, 2 * E, F, D, false, w.wp[0], w.wp[1], s));
+    MDM_TRY(pack_planes(P->w2, 2 * E, D, F, false, w.wp[2], w.wp[3], s));
+    MDM_TRY(pack_planes(P->w1, 2 * E, F, D, true, w.wp[4], w.wp[5], s));
+    MDM_TRY(pack_planes(P->w2, 2 * E, D, F, true, w.wp[6], w.wp[7], s));
+  }
   {
     GemmArgs g = x3();  // pre = xg W1_e^T + b1_e                      (switch_moe.py:19-21)
-    g.A = op_f32(w.xg, D), g.W = op_f32(P->w1, D), g.W.bs1 = (int64_t)F * D;
+    g.A = op_f32(w.xg, D), g.W = planes ? op_bf16(w.wp[0], w.wp[1], D) : op_f32(P->w1, D), g.W.bs1 = (int64_t)F * D;
     g.goff = w.goff, g.ngroups = 2 * E, g.M = (int)(4 * M), g.N = F, g.K = D;
     g.bias = P->b1, g.bias_bs = F, g.C = w.pre, g.ldc = F;
     MDM_TRY(gemm(g, s));
@@ -596,7 +638,7 @@ extern "C" int mdm_moe_ffn_train_forward(const MdmMoeTensors* P, int32_t D, int3
   hipLaunchKernelGGL(ew_kernel<0>, dim3(ew_grid(4 * M * F)), dim3(256), 0, s, (const float*)w.pre, w.hid, 4 * M * F);
   {
     GemmArgs g = x3();  // y2 = p * (hid W2_e^T + b2_e)                (:24,108-109)
-    g.A = op_f32(w.hid, F), g.W = op_f32(P->w2, F), g.W.bs1 = (int64_t)D * F;
+    g.A = op_f32(w.hid, F), g.W = planes ? op_bf16(w.wp[2], w.wp[3], F) : op_f32(P->w2, F), g.W.bs1 = (int64_t)D * F;
     g.goff = w.goff, g.ngroups = 2 * E, g.M = (int)(4 * M), g.N = D, g.K = F;
     g.bias = P->b2, g.bias_bs = D, g.rowscale = w.rowscale, g.C = w.y2, g.ldc = D;
     MDM_TRY(gemm(g, s));
@@ -709,7 +751,8 @@ extern "C" int mdm_moe_ffn_train_backward(const MdmMoeTensors* P, int32_t D, int
   MDM_TRY(colsum(w.dy, D, 4 * M, D, w.goff, 2 * E, 0, G->b2, s));
   {
     GemmArgs g = x3();  // d hid = dy W2_e  (over the hidden buffer, dead after dW2)
-    g.A = op_f32(w.dy, D), g.W = op_f32_kstride(P->w2, F), g.W.bs1 = (int64_t)D * F;
+    // W2_e^T rows (f, k = d): the transposed planes packed by the forward, or the fp32 weight read k-strided
+    g.A = op_f32(w.dy, D), g.W = planes_ok(D, F) ? op_bf16(w.wp[6], w.wp[7], D) : op_f32_kstride(P->w2, F), g.W.bs1 = (int64_t)D * F;
     g.goff = w.goff, g.ngroups = 2 * E, g.M = (int)(4 * M), g.N = F, g.K = D, g.C = w.hid, g.ldc = F;
     MDM_TRY(gemm(g, s));
   }
@@ -723,7 +766,7 @@ extern "C" int mdm_moe_ffn_train_backward(const MdmMoeTensors* P, int32_t D, int
   MDM_TRY(colsum(w.hid, F, 4 * M, F, w.goff, 2 * E, 0, G->b1, s));
   {
     GemmArgs g = x3();  // d xg = dpre W1_e  (over the dy buffer, dead by now)
-    g.A = op_f32(w.hid, F), g.W = op_f32_kstride(P->w1, D), g.W.bs1 = (int64_t)F * D;
+    g.A = op_f32(w.hid, F), g.W = planes_ok(D, F) ? op_bf16(w.wp[4], w.wp[5], F) : op_f32_kstride(P->w1, D), g.W.bs1 = (int64_t)F * D;
     g.goff = w.goff, g.ngroups = 2 * E, g.M = (int)(4 * M), g.N = D, g.K = F, g.C = w.dy, g.ldc = D;
     MDM_TRY(gemm(g, s));
   }
