@@ -169,7 +169,7 @@ def test_configs3_ddim_steps_of_a_100_step_schedule():
 
 
 @pytest.mark.parametrize("precision,tol", [(2, 6e-4), (1, 4e-3)])
-@pytest.mark.parametrize("S", [40, 98, 196])
+@pytest.mark.parametrize("S", [40, 98, 196, 17, 224])  # 17: one full + one ragged tile; 224: the largest S the kernels take
 def test_big_width_performer_core_fused_kernel(S, precision, tol):
     """head_dim 256 (big model): mdm_performer_attn_forward runs the fused core of csrc/perf_attn2.hip (feature / value halves,
     KV^T through an L2-resident scratch) in the 16-bit modes -- against the oracle's PerformerSelfAttention, both attention
@@ -217,7 +217,7 @@ def test_big_width_performer_core_fused_kernel(S, precision, tol):
 
 
 @pytest.mark.parametrize("precision,tol", [(2, 6e-3), (1, 3e-2)])
-@pytest.mark.parametrize("S,N", [(196, 28), (98, 9), (37, 85)])
+@pytest.mark.parametrize("S,N", [(196, 28), (98, 9), (37, 85), (5, 96), (1, 1)])  # 96: the largest N of the softmax core
 def test_big_width_linear_cross_attention_fused_core(S, N, precision, tol):
     """head_dim 256: GatedCrossAttention (fast_attention.py:242-272) through mdm_block_forward runs the fused
     softmax_dh(q) A core of csrc/xattn.hip (lin_xattn256_kernel: A^T of one (batch, head) resident in 132 KiB of LDS) in the
