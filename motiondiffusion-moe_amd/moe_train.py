@@ -98,6 +98,12 @@ class MoEFFNTrainer:
                 out[k] = t.detach().clone()
         return out
 
+    def _same_device(self, *tensors):
+        dev = self.params.flat.device
+        for t in tensors:
+            if t is not None and t.device != dev:
+                raise L.MdmError(f"tensor on {t.device}, block on {dev}: the HIP path does not copy across devices")
+
     # ---- forward / backward ---------------------------------------------------------------------------------------------------
     def _workspace(self, B: int, S: int) -> torch.Tensor:
         if self._shape != (B, S):
@@ -112,6 +118,7 @@ class MoEFFNTrainer:
                 route_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x (B, S, D), emb (B, De); eph = (weight (Te, De), bias (Te)) of the captured per-call projection when De != Te."""
         L.require_cuda(x, emb)
+        self._same_device(x, emb, *(eph or ()))
         B, S, D = x.shape
         De = emb.shape[-1]
         if D != self.D or emb.shape[0] != B:
@@ -145,6 +152,7 @@ class MoEFFNTrainer:
             raise L.MdmError("backward() without a forward()")
         x, emb, ew, B, S, De, mask_seed = self._saved
         L.require_cuda(dout)
+        self._same_device(dout)
         dout = dout.contiguous().float()
         if tuple(dout.shape) != (B, S, self.D):
             raise L.MdmError("dout has the wrong shape")
