@@ -192,8 +192,10 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
 // matrices of both branches sit in LDS, and the 2E logits are reduced with 4-step group shuffles (the one-token-per-
 // wave version above spends its time in 2E full-wave reductions).  Requires D % 64 == 0.
 template <int NV>  // float4 per lane: D = 64 * NV
-__global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict__ x, int64_t M, int D, int E,
+__global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict__ x, int64_t M, int D_rt, int E,
                                                          MoeGateParams p) {
+  constexpr int D = 64 * NV;  // (== D_rt: the host dispatches on D / 64) -- a compile-time row length folds the gate-row and
+                              // output addresses into immediates
   extern __shared__ __attribute__((aligned(16))) float gsm[];  // [2][E][D] gate weights, then counters
   float* gw = gsm;
   int* s_hist = (int*)(gsm + 2 * E * D);
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
         for (int e = 0; e < 16; ++e)
           if (e < E) {
             const f32x4 g = *(const f32x4*)(gw + (br * E + e) * D + k);
-            logit[e] += h[0] * g[0] + h[1] * g[1] + h[2] * g[2] + h[3] * g[3];
+            // explicit FMA chain: written as a sum of products hipcc SLP-packs the four multiplies (v_pk_mul_f32) and adds
+            // the results one by one -- 1626 VALU instructions per token group where 1024 FMAs do
+            logit[e] = __builtin_fmaf(h[3], g[3], __builtin_fmaf(h[2], g[2], __builtin_fmaf(h[1], g[1], __builtin_fmaf(h[0], g[0], logit[e]))));
           }
       }
       if (p.hn_bf16 == 3) {  // e4m3 rows, scale = amax / 448 (the LayerNorm output is recomputed: cheaper than keeping it)
