@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const float* __restrict__
 // Router, 16 lanes per token (4 tokens per wave): one set of LayerNorm statistics serves both branches, the gate
 // matrices of both branches sit in LDS, and the 2E logits are reduced with 4-step group shuffles (the one-token-per-
 // wave version above spends its time in 2E full-wave reductions).  Requires D % 64 == 0.
-template <int NV>  // float4 per lane: D = 64 * NV
+// FAST (the 16-bit / fp8 modes, whose routing differences from the fp32-grade mode are budgeted anyway): gate logits as an
+// explicit FMA chain; otherwise the sum-of-products form the fp32-grade mode has always used (its near-tie decisions are
+// pinned by the parity tests, and a different association resolves some of them differently).
+template <int NV, bool FAST>  // float4 per lane: D = 64 * NV
 __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict__ x, int64_t M, int D_rt, int E,
                                                          MoeGateParams p) {
   constexpr int D = 64 * NV;  // (== D_rt: the host dispatches on D / 64) -- a compile-time row length folds the gate-row and
@@ -252,9 +255,13 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
         for (int e = 0; e < 16; ++e)
           if (e < E) {
             const f32x4 g = *(const f32x4*)(gw + (br * E + e) * D + k);
-            // explicit FMA chain: written as a sum of products hipcc SLP-packs the four multiplies (v_pk_mul_f32) and adds
-            // the results one by one -- 1626 VALU instructions per token group where 1024 FMAs do
-            logit[e] = __builtin_fmaf(h[3], g[3], __builtin_fmaf(h[2], g[2], __builtin_fmaf(h[1], g[1], __builtin_fmaf(h[0], g[0], logit[e]))));
+            if constexpr (FAST) {
+              // explicit FMA chain: written as a sum of products hipcc SLP-packs the four multiplies (v_pk_mul_f32) and adds
+              // the results one by one -- 1626 VALU instructions per token group where 1024 FMAs do
+              logit[e] = __builtin_fmaf(h[3], g[3], __builtin_fmaf(h[2], g[2], __builtin_fmaf(h[1], g[1], __builtin_fmaf(h[0], g[0], logit[e]))));
+            } else {
+              logit[e] += h[0] * g[0] + h[1] * g[1] + h[2] * g[2] + h[3] * g[3];
+            }
           }
       }
       if (p.hn_bf16 == 3) {  // e4m3 rows, scale = amax / 448 (the LayerNorm output is recomputed: cheaper than keeping it)
@@ -725,18 +732,29 @@ int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, i
     nparts = grid;
     static int attr_done = 0;
     if (smem > 65536 && smem > attr_done) {
-      const void* fn = D == 1024 ? (const void*)moe_gate16_kernel<16> : (const void*)moe_gate16_kernel<8>;
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return MDM_ERR_LAUNCH;
+      const void* fns[4] = {(const void*)moe_gate16_kernel<16, true>, (const void*)moe_gate16_kernel<16, false>,
+                            (const void*)moe_gate16_kernel<8, true>, (const void*)moe_gate16_kernel<8, false>};
+      for (const void* fn : fns)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return MDM_ERR_LAUNCH;
       attr_done = smem;
     }
+#define GATE16(NV)                                                                                            \
+  do {                                                                                                        \
+    if (p.hn_bf16) {                                                                                          \
+      hipLaunchKernelGGL((moe_gate16_kernel<NV, true>), dim3(grid), dim3(256), smem, s, x, M, D, E, p);       \
+    } else {                                                                                                  \
+      hipLaunchKernelGGL((moe_gate16_kernel<NV, false>), dim3(grid), dim3(256), smem, s, x, M, D, E, p);      \
+    }                                                                                                         \
+  } while (0)
     switch (D / 64) {
-      case 1: hipLaunchKernelGGL(moe_gate16_kernel<1>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
-      case 2: hipLaunchKernelGGL(moe_gate16_kernel<2>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
-      case 4: hipLaunchKernelGGL(moe_gate16_kernel<4>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
-      case 8: hipLaunchKernelGGL(moe_gate16_kernel<8>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
-      case 16: hipLaunchKernelGGL(moe_gate16_kernel<16>, dim3(grid), dim3(256), smem, s, x, M, D, E, p); break;
+      case 1: GATE16(1); break;
+      case 2: GATE16(2); break;
+      case 4: GATE16(4); break;
+      case 8: GATE16(8); break;
+      case 16: GATE16(16); break;
       default: return MDM_ERR_UNSUPPORTED;
     }
+#undef GATE16
   } else {
   const int gate_grid = row_grid(M) > 512 ? 512 : row_grid(M);
   nparts = gate_grid;
