@@ -117,6 +117,42 @@ def test_forward_shape_sweep_both_modes(B, T, N):
     assert e3 < TOL_FP32 and e1 < 5e-2
 
 
+def test_zero_and_unit_length_samples_match_the_oracle():
+    """Degenerate lengths: a sample with NO valid frame (every Performer key masked: the denominator clamp of
+    fast_attention.py:82 decides the output), one with a single frame and one odd length whose half-scale length rounds down
+    (transformer.py:341-342), next to a full-length sample -- fp32-grade and f16 (routing injected) against the oracle."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import denoiser_ref as R
+    synth = pkg("synth")
+    g, meta = load_golden("fwd_small_dims")
+    B, T, N = 4, 24, 7
+    x = synth.uniform_pm1((B, T, 263), "deg.x", 5) * (3.0 ** 0.5)
+    xf_out = synth.uniform_pm1((B, N, 256), "deg.xf", 5) * (3.0 ** 0.5)
+    xf_proj = xf_out.mean(1)
+    length = torch.tensor([T, 0, 1, 13])
+    ts = torch.tensor([999, 0, 500, 17])
+    trace = {}
+    m3, (sd, eph, proj, mcfg) = build_module(meta, precision=3)
+    with torch.no_grad():
+        ref = R.denoiser_forward(sd, mcfg, x, ts, length, xf_proj, xf_out, eph, proj, None, trace)
+    assert torch.isfinite(ref).all()
+    forced = torch.zeros((2, 2 * 2 * B * T), dtype=torch.int32)
+    for li, name in enumerate(_layer_names(1)):
+        idx = torch.stack([trace[f"{name}.ffn.branches.{b}.top2_idx"] for b in range(2)])
+        forced[li, :idx.numel()] = idx.reshape(-1).to(torch.int32)
+    args = (x.cuda(), ts.cuda(), length.cuda())
+    kw = dict(xf_proj=xf_proj.cuda(), xf_out=xf_out.cuda())
+    y3 = m3(*args, **kw).cpu()
+    m2, _ = build_module(meta, precision=2)
+    y2 = m2(*args, forced_routing=forced, **kw).cpu()
+    e3, e2 = rel_inf(y3, ref), rel_inf(y2, ref)
+    print(f"lengths {length.tolist()}: fp32-grade {e3:.2e}, f16 (routing injected) {e2:.2e}")
+    assert torch.isfinite(y3).all() and torch.isfinite(y2).all()
+    assert e3 < TOL_FP32 and e2 < 1e-2
+
+
 def test_probe_brackets_every_expert_mlp_launch():
     """mdm_probe_enable / mdm_probe_read (bench.py's live timing of the dominant kernel): one event pair per fused expert
     MLP launch of a throughput-mode forward, with that launch's routed-row count."""
