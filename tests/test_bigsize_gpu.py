@@ -181,10 +181,10 @@ def test_big_width_performer_core_fused_kernel(S, precision, tol):
     m, (sd, eph, proj, mcfg) = build_module(meta, precision=precision)
     L, synth = pkg("_lib"), pkg("synth")
     lib, pm = L.lib(), m.pack()
-    D, H, B = 1024, 4, 3
+    D, H, B = 1024, 4, 4
     h = synth.uniform_pm1((B, S, D), "blk.h", S) * 1.5
     emb = synth.uniform_pm1((B, D), "blk.emb", S)
-    length = torch.tensor([S, max(1, S - 13), max(1, S // 2)])
+    length = torch.tensor([S, max(1, S - 13), max(1, S // 2), 0])  # the last sample has every key masked
     pre = "decoder_blocks_low.0.module"
     mask = R.src_mask(S, length)
     ws = m._workspace(B, S, 1)
