@@ -24,7 +24,9 @@ namespace mdm {
 namespace {
 
 constexpr int DH2 = 256, PS2 = 264, NW2 = 8, NTH2 = 64 * NW2;
-constexpr int R_BIG = DH2 * PS2 * 2;             // 135168: P^T [256][264]; in the second kernel v images, then KV^T [256][264]
+constexpr int R_BIG = DH2 * PS2 * 2;             // 135168 >= P^T / KV^T images [256][256] with 512-B rows whose 16-B chunk c sits at
+                                                 // slot c ^ (row & 15): conflict-free for the measured ds_read_b128 lane groups (a row
+                                                 // padded by 16 B, 264 elements, costs one 2-way collision per 16-lane group = 2x cycles)
 constexpr int SMEM_PA2 = R_BIG + 2 * DH2 * 4;    // + LN gain | bias
 
 typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(NTH2, 2) void perf_feat256_kernel(const uint16_t* _
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = tid + NTH2 * (k0 + k);
-      *(uint4*)(P + (i >> 5) * PS2 + (i & 31) * 8) = tmp[k];
+      *(uint4*)((uint8_t*)P + (i >> 5) * 512 + ((((i & 31) ^ ((i >> 5) & 15))) << 4)) = tmp[k];  // 512-B rows, chunk ^ (row & 15)
     }
   }
   __syncthreads();
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(NTH2, 2) void perf_feat256_kernel(const uint16_t* _
       for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          const frag_t p = *(const frag_t*)(P + (128 * half + 16 * mt + r16) * PS2 + 32 * ks + 8 * q);
+          const int pr = 128 * half + 16 * mt + r16;
+          const frag_t p = *(const frag_t*)((const uint8_t*)P + pr * 512 + (((4 * ks + q) ^ (pr & 15)) << 4));
           aT[mt] = HT::mfma16(kf[ks], p, aT[mt]);  // D[t][m]: lane col m = r16, rows t = 4 q + r
           aQ[mt] = HT::mfma16(p, qf[ks], aQ[mt]);  // D[m][t]: lane col t = r16, rows m = 4 q + r
           aK[mt] = HT::mfma16(p, kf[ks], aK[mt]);
@@ -279,8 +282,11 @@ __global__ __launch_bounds__(NTH2, 2) void perf_kvnum256_kernel(const uint16_t* 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        *(uint2*)(kv + (128 * wdh + 16 * j + r16) * PS2 + 64 * wmq + 16 * i + 4 * q) =
+      {
+        const int kr = 128 * wdh + 16 * j + r16, kc = 64 * wmq + 16 * i + 4 * q;  // row d, first column m of this lane's 4
+        *(uint2*)((uint8_t*)kv + kr * 512 + (((kc >> 3) ^ (kr & 15)) << 4) + ((kc >> 2) & 1) * 8) =
             make_uint2(HT::pack(0.1f * acc[i][j][0], 0.1f * acc[i][j][1]), HT::pack(0.1f * acc[i][j][2], 0.1f * acc[i][j][3]));
+      }
   }
   __syncthreads();
 
@@ -303,7 +309,8 @@ __global__ __launch_bounds__(NTH2, 2) void perf_kvnum256_kernel(const uint16_t* 
   for (int dt = 0; dt < 16; ++dt) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const frag_t av = *(const frag_t*)(kv + (16 * dt + r16) * PS2 + 32 * ks + 8 * q);
+      const int kr = 16 * dt + r16;
+      const frag_t av = *(const frag_t*)((const uint8_t*)kv + kr * 512 + (((4 * ks + q) ^ (kr & 15)) << 4));
 #pragma unroll
       for (int n = 0; n < NT; ++n) accn[n][dt] = HT::mfma16(av, bq[n][ks], accn[n][dt]);  // lane col t = r16, rows d = 4 q + r
     }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
   for (int i = tid; i < DH * (DH / 4); i += XNT) {
     const int l = i / (DH / 4), c = i - l * (DH / 4);
     const f32x4 v = *(const f32x4*)(ab + l * DH + 4 * c);
-    *(uint2*)(aL + l * PS + 4 * c) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
+    *(uint2*)((uint8_t*)aL + l * 256 + (((c >> 1) ^ (l & 15)) << 4) + (c & 1) * 8) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
   }
   __syncthreads();
   const int ntile = (S + 15) >> 4;
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int lt = 0; lt < 8; ++lt) {
-        const frag_t af = *(const frag_t*)(aL + (16 * lt + r16) * PS + 32 * ks + 8 * q);
+        const int ar = 16 * lt + r16;  // 256-B rows, 16-B chunk c at slot c ^ (row & 15): conflict-free ds_read_b128
+        const frag_t af = *(const frag_t*)((const uint8_t*)aL + ar * 256 + (((4 * ks + q) ^ (ar & 15)) << 4));
         y[lt] = HT::mfma16(af, qf[ks], y[lt]);  // D[l][t]
       }
     if (t < S && out16) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(XNT, 2) void lin_xattn256_kernel(const void* __rest
   for (int i = tid; i < DH2 * (DH2 / 4); i += XNT) {
     const int l = i / (DH2 / 4), c = i - l * (DH2 / 4);
     const f32x4 v = *(const f32x4*)(ab + l * DH2 + 4 * c);
-    *(uint2*)(aL2 + l * PS2 + 4 * c) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
+    *(uint2*)((uint8_t*)aL2 + l * 512 + (((c >> 1) ^ (l & 15)) << 4) + (c & 1) * 8) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
   }
   __syncthreads();
   const int ntile = (S + 15) >> 4;
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(XNT, 2) void lin_xattn256_kernel(const void* __rest
     for (int lt = 0; lt < 16; ++lt) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const frag_t af = *(const frag_t*)(aL2 + (16 * lt + r16) * PS2 + 32 * ks + 8 * q);
+        const int ar = 16 * lt + r16;
+        const frag_t af = *(const frag_t*)((const uint8_t*)aL2 + ar * 512 + (((4 * ks + q) ^ (ar & 15)) << 4));
         y[lt] = HT::mfma16(af, qf[ks], y[lt]);  // D[l][t]
       }
       if ((lt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
