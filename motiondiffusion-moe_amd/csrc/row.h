@@ -29,20 +29,33 @@ struct Row {
       }
     }
   }
-  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ p, int D, int lane, int fmt = 1) {
+  // 16-bit rows.  FMT (1 = bf16, 2 = fp16) is a template argument on purpose: with the format as a run-time value every
+  // converted element carries a uniform branch, and hipcc then waits for each 8-byte load before it issues the next one
+  // (the loads of a row, and of the rows a kernel gathers, must all be in flight together).
+  template <int FMT>
+  __device__ __forceinline__ void load_h16(const uint16_t* __restrict__ p, int D, int lane) {
     if constexpr (VEC) {
+      uint2 u[NE / 4];
+#pragma unroll
+      for (int c = 0; c < NE / 4; ++c) u[c] = *(const uint2*)(p + 4 * (lane + 64 * c));
 #pragma unroll
       for (int c = 0; c < NE / 4; ++c) {
-        const uint2 u = *(const uint2*)(p + 4 * (lane + 64 * c));
-        e[4 * c + 0] = h16_lo_f32(fmt, u.x), e[4 * c + 1] = h16_hi_f32(fmt, u.x);
-        e[4 * c + 2] = h16_lo_f32(fmt, u.y), e[4 * c + 3] = h16_hi_f32(fmt, u.y);
+        e[4 * c + 0] = h16_lo_f32(FMT, u[c].x), e[4 * c + 1] = h16_hi_f32(FMT, u[c].x);
+        e[4 * c + 2] = h16_lo_f32(FMT, u[c].y), e[4 * c + 3] = h16_hi_f32(FMT, u[c].y);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
         const int i = lane + 64 * j;
-        e[j] = i < D ? h16_lo_f32(fmt, (uint32_t)p[i]) : 0.f;
+        e[j] = i < D ? h16_lo_f32(FMT, (uint32_t)p[i]) : 0.f;
       }
+    }
+  }
+  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ p, int D, int lane, int fmt = 1) {
+    if (fmt == 2) {
+      load_h16<2>(p, D, lane);
+    } else {
+      load_h16<1>(p, D, lane);
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ p, int D, int lane) const {
@@ -60,18 +73,35 @@ struct Row {
       }
     }
   }
-  // bf16 (round-to-nearest-even) copy of the row, for tensors whose only consumer is a bf16 MFMA GEMM
-  __device__ __forceinline__ void store_bf16(uint16_t* __restrict__ p, int D, int lane, int fmt = 1) const {
+  // 16-bit (round-to-nearest-even) copy of the row, for tensors whose only consumer is a 16-bit MFMA GEMM
+  template <int FMT>
+  __device__ __forceinline__ void store_h16(uint16_t* __restrict__ p, int D, int lane) const {
     if constexpr (VEC) {
 #pragma unroll
       for (int c = 0; c < NE / 4; ++c)
-        *(uint2*)(p + 4 * (lane + 64 * c)) = make_uint2(pack_h16(fmt, e[4 * c + 0], e[4 * c + 1]), pack_h16(fmt, e[4 * c + 2], e[4 * c + 3]));
+        *(uint2*)(p + 4 * (lane + 64 * c)) = make_uint2(pack_h16(FMT, e[4 * c + 0], e[4 * c + 1]), pack_h16(FMT, e[4 * c + 2], e[4 * c + 3]));
     } else {
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
         const int i = lane + 64 * j;
-        if (i < D) p[i] = (uint16_t)(pack_h16(fmt, e[j], 0.f) & 0xffff);
+        if (i < D) p[i] = (uint16_t)(pack_h16(FMT, e[j], 0.f) & 0xffff);
       }
+    }
+  }
+  __device__ __forceinline__ void store_bf16(uint16_t* __restrict__ p, int D, int lane, int fmt = 1) const {
+    if (fmt == 2) {
+      store_h16<2>(p, D, lane);
+    } else {
+      store_h16<1>(p, D, lane);
+    }
+  }
+  // fp32 or 16-bit destination, format fixed at compile time
+  template <int FMT>
+  __device__ __forceinline__ void store_to(void* __restrict__ p, int64_t row, int D, int lane, bool h16) const {
+    if (h16) {
+      store_h16<FMT>((uint16_t*)p + row * D, D, lane);
+    } else {
+      store((float*)p + row * D, D, lane);
     }
   }
   __device__ __forceinline__ void store_as(void* __restrict__ p, int64_t row, int D, int lane, int bf16) const {
@@ -88,7 +118,8 @@ struct Row {
     return wave_sum(s);
   }
   // LayerNorm in place (eps 1e-5, biased variance, two-pass like ATen); padded lanes stay 0
-  __device__ __forceinline__ void layernorm(const float* __restrict__ w, const float* __restrict__ b, int D, int lane) {
+  // (weight / bias rows already in registers: the row kernels request them before the data rows arrive)
+  __device__ __forceinline__ void layernorm(const Row<NE, VEC>& ww, const Row<NE, VEC>& bb, int D, int lane) {
     const float mean = sum() / D;
     float s = 0.f;
 #pragma unroll
@@ -98,14 +129,17 @@ struct Row {
       s += d * d;
     }
     const float rstd = rsqrtf(wave_sum(s) / D + 1e-5f);
-    Row<NE, VEC> ww, bb;
-    ww.load(w, D, lane);
-    bb.load(b, D, lane);
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
       const bool in = VEC || (lane + 64 * j < D);
       e[j] = in ? (e[j] - mean) * rstd * ww.e[j] + bb.e[j] : 0.f;
     }
+  }
+  __device__ __forceinline__ void layernorm(const float* __restrict__ w, const float* __restrict__ b, int D, int lane) {
+    Row<NE, VEC> ww, bb;
+    ww.load(w, D, lane);
+    bb.load(b, D, lane);
+    layernorm(ww, bb, D, lane);
   }
 };
 

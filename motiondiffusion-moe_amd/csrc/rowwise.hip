@@ -8,34 +8,49 @@ namespace mdm {
 namespace {
 
 // ---- LN chain: y1 = LN1(x), y2 = LN2(y1) --------------------------------------------------------
-template <int NE, bool VEC>
-__global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, int x_bf, int64_t M, int D,
-                                                       const float* w1, const float* b1, void* y1, int y1_bf,
-                                                       const float* w2, const float* b2, void* y2, int y2_bf) {
+// FMT = the 16-bit format of whichever tensors are 16-bit (1 = bf16, 2 = fp16; one format per launch), a template argument so
+// that the conversions are straight-line code and every load of an iteration is issued before the first wait (row.h)
+template <int NE, bool VEC, int FMT>
+__device__ __forceinline__ void ln_chain_rows(const float* __restrict__ x, bool x_h, int64_t M, int D, const float* w1,
+                                              const float* b1, void* y1, bool y1_h, const float* w2, const float* b2,
+                                              void* y2, bool y2_h) {
   const int lane = threadIdx.x & 63;
+  Row<NE, VEC> ww1, bb1, ww2, bb2;
+  ww1.load(w1, D, lane), bb1.load(b1, D, lane);
+  if (w2) ww2.load(w2, D, lane), bb2.load(b2, D, lane);
   // two rows per wave per iteration: both rows' loads are in flight before either is reduced
   for (int64_t row = 2 * (blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6)); row < M; row += 2 * (int64_t)gridDim.x * WPB) {
     const bool two = row + 1 < M;
     Row<NE, VEC> r, q;
-    if (x_bf) {
-      r.load_bf16((const uint16_t*)x + row * D, D, lane, x_bf);
-      q.load_bf16((const uint16_t*)x + (two ? row + 1 : row) * D, D, lane, x_bf);
+    if (x_h) {
+      r.template load_h16<FMT>((const uint16_t*)x + row * D, D, lane);
+      q.template load_h16<FMT>((const uint16_t*)x + (two ? row + 1 : row) * D, D, lane);
     } else {
       r.load(x + row * D, D, lane);
       q.load(x + (two ? row + 1 : row) * D, D, lane);
     }
-    r.layernorm(w1, b1, D, lane);
-    q.layernorm(w1, b1, D, lane);
+    r.layernorm(ww1, bb1, D, lane);
+    q.layernorm(ww1, bb1, D, lane);
     if (y1) {
-      r.store_as(y1, row, D, lane, y1_bf);
-      if (two) q.store_as(y1, row + 1, D, lane, y1_bf);
+      r.template store_to<FMT>(y1, row, D, lane, y1_h);
+      if (two) q.template store_to<FMT>(y1, row + 1, D, lane, y1_h);
     }
     if (w2) {
-      r.layernorm(w2, b2, D, lane);
-      q.layernorm(w2, b2, D, lane);
-      r.store_as(y2, row, D, lane, y2_bf);
-      if (two) q.store_as(y2, row + 1, D, lane, y2_bf);
+      r.layernorm(ww2, bb2, D, lane);
+      q.layernorm(ww2, bb2, D, lane);
+      r.template store_to<FMT>(y2, row, D, lane, y2_h);
+      if (two) q.template store_to<FMT>(y2, row + 1, D, lane, y2_h);
     }
+  }
+}
+template <int NE, bool VEC>
+__global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, int x_bf, int64_t M, int D,
+                                                       const float* w1, const float* b1, void* y1, int y1_bf,
+                                                       const float* w2, const float* b2, void* y2, int y2_bf) {
+  if ((x_bf | y1_bf | y2_bf) == 2) {
+    ln_chain_rows<NE, VEC, 2>(x, x_bf != 0, M, D, w1, b1, y1, y1_bf != 0, w2, b2, y2, y2_bf != 0);
+  } else {
+    ln_chain_rows<NE, VEC, 1>(x, x_bf != 0, M, D, w1, b1, y1, y1_bf != 0, w2, b2, y2, y2_bf != 0);
   }
 }
 
@@ -43,40 +58,47 @@ __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__
 // a = x                                               (cross / ffn blocks, stylization.py:29-30)
 // a = normalize(LN_post(x)) * sqrt(D)                  (Performer tail, fast_attention.py:169-172)
 // a = 0.5 * sum of the 4 routed expert rows            (MoE combine, switch_moe.py:109 + multi_branch.py:58-59)
-template <int NE, bool VEC>
-__global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__ x, int64_t M, int D, int S,
-                                                       const float* pw, const float* pb,  // optional post_norm
-                                                       const float* sw, const float* sb,  // style norm
-                                                       const float* __restrict__ sc,      // (B, 2D) scale|shift
-                                                       const int* __restrict__ pos4,      // optional (M,4) rows of y2
-                                                       int x_bf,                           // y2 rows are bf16
-                                                       void* __restrict__ out, int out_bf) {
+template <int NE, bool VEC, int FMT>
+__device__ __forceinline__ void style_in_rows(const float* __restrict__ x, int64_t M, int D, int S, const float* pw,
+                                              const float* pb, const float* sw, const float* sb,
+                                              const float* __restrict__ sc, const int* __restrict__ pos4, bool x_h,
+                                              void* __restrict__ out, bool out_h) {
   const int lane = threadIdx.x & 63;
+  Row<NE, VEC> pww, pbb, sww, sbb;  // requested before the data rows, not after the reductions that precede their use
+  if (pw) pww.load(pw, D, lane), pbb.load(pb, D, lane);
+  sww.load(sw, D, lane), sbb.load(sb, D, lane);
   for (int64_t row = blockIdx.x * (int64_t)WPB + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * WPB) {
-    Row<NE, VEC> r;
+    const float* scb = sc + (row / S) * 2 * (int64_t)D;
+    Row<NE, VEC> r, scale, shift;
+    scale.load(scb, D, lane);  // first: they depend on the row number only, and must not queue behind the gathered rows' wait
+    shift.load(scb + D, D, lane);
     if (pos4) {
+      // the token's four routed rows: one 16-byte read of their positions, then all four rows in flight together
+      const int p0 = pos4[row * 4 + 0], p1 = pos4[row * 4 + 1], p2 = pos4[row * 4 + 2], p3 = pos4[row * 4 + 3];
       Row<NE, VEC> a, b, c, d;
-      if (x_bf) {
+      if (x_h) {
         const uint16_t* xh = (const uint16_t*)x;
-        a.load_bf16(xh + (int64_t)pos4[row * 4 + 0] * D, D, lane, x_bf);
-        b.load_bf16(xh + (int64_t)pos4[row * 4 + 1] * D, D, lane, x_bf);
-        c.load_bf16(xh + (int64_t)pos4[row * 4 + 2] * D, D, lane, x_bf);
-        d.load_bf16(xh + (int64_t)pos4[row * 4 + 3] * D, D, lane, x_bf);
+        a.template load_h16<FMT>(xh + (int64_t)p0 * D, D, lane);
+        b.template load_h16<FMT>(xh + (int64_t)p1 * D, D, lane);
+        c.template load_h16<FMT>(xh + (int64_t)p2 * D, D, lane);
+        d.template load_h16<FMT>(xh + (int64_t)p3 * D, D, lane);
       } else {
-        a.load(x + (int64_t)pos4[row * 4 + 0] * D, D, lane);
-        b.load(x + (int64_t)pos4[row * 4 + 1] * D, D, lane);
-        c.load(x + (int64_t)pos4[row * 4 + 2] * D, D, lane);
-        d.load(x + (int64_t)pos4[row * 4 + 3] * D, D, lane);
+        a.load(x + (int64_t)p0 * D, D, lane);
+        b.load(x + (int64_t)p1 * D, D, lane);
+        c.load(x + (int64_t)p2 * D, D, lane);
+        d.load(x + (int64_t)p3 * D, D, lane);
       }
 #pragma unroll
       for (int j = 0; j < NE; ++j) r.e[j] = ((a.e[j] + b.e[j]) + (c.e[j] + d.e[j])) * 0.5f;
-    } else if (x_bf) {
-      r.load_bf16((const uint16_t*)x + row * D, D, lane, x_bf);
     } else {
-      r.load(x + row * D, D, lane);
+      if (x_h) {
+        r.template load_h16<FMT>((const uint16_t*)x + row * D, D, lane);
+      } else {
+        r.load(x + row * D, D, lane);
+      }
     }
     if (pw) {
-      r.layernorm(pw, pb, D, lane);
+      r.layernorm(pww, pbb, D, lane);
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < NE; ++j) s += r.e[j] * r.e[j];
@@ -84,14 +106,24 @@ __global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < NE; ++j) r.e[j] *= inv;
     }
-    r.layernorm(sw, sb, D, lane);
-    const float* scb = sc + (row / S) * 2 * (int64_t)D;
-    Row<NE, VEC> scale, shift;
-    scale.load(scb, D, lane);
-    shift.load(scb + D, D, lane);
+    r.layernorm(sww, sbb, D, lane);
 #pragma unroll
     for (int j = 0; j < NE; ++j) r.e[j] = silu(r.e[j] * (1.f + scale.e[j]) + shift.e[j]);
-    r.store_as(out, row, D, lane, out_bf);
+    r.template store_to<FMT>(out, row, D, lane, out_h);
+  }
+}
+template <int NE, bool VEC>
+__global__ __launch_bounds__(256) void style_in_kernel(const float* __restrict__ x, int64_t M, int D, int S,
+                                                       const float* pw, const float* pb,  // optional post_norm
+                                                       const float* sw, const float* sb,  // style norm
+                                                       const float* __restrict__ sc,      // (B, 2D) scale|shift
+                                                       const int* __restrict__ pos4,      // optional (M,4) rows of y2
+                                                       int x_bf,                           // 16-bit source rows (format code)
+                                                       void* __restrict__ out, int out_bf) {
+  if ((x_bf | out_bf) == 2) {
+    style_in_rows<NE, VEC, 2>(x, M, D, S, pw, pb, sw, sb, sc, pos4, x_bf != 0, out, out_bf != 0);
+  } else {
+    style_in_rows<NE, VEC, 1>(x, M, D, S, pw, pb, sw, sb, sc, pos4, x_bf != 0, out, out_bf != 0);
   }
 }
 
@@ -204,25 +236,52 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
   int* s_hist = (int*)(gsm + 2 * E * D);
   float* s_usage = (float*)(s_hist + 32);
   float* s_imp = s_usage + 32;
-  for (int i = threadIdx.x; i < 2 * E * D / 4; i += 256) {
-    const int br = (4 * i) / (E * D), off = 4 * i - br * E * D;
-    *(f32x4*)(gw + 4 * i) = *(const f32x4*)(p.gate_w[br] + off);
+  const int l16 = threadIdx.x & 15;
+  const int64_t tpb = 16;  // tokens per block iteration
+  const int64_t stride = (int64_t)gridDim.x * tpb;
+  auto load_x = [&](int64_t base, f32x4(&r)[NV]) {
+    const int64_t row = base + (threadIdx.x >> 4);
+    const int64_t rc = row < M ? row : M - 1;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) r[c] = *(const f32x4*)(x + rc * D + 4 * (l16 + 16 * c));
+  };
+  // the first token rows are requested before the gate matrices are staged, so that their latency runs under the staging
+  f32x4 vn[NV];
+  if constexpr (NV <= 8)
+    if (blockIdx.x * tpb < M) load_x(blockIdx.x * tpb, vn);
+  // gate matrices -> LDS, four 16-B loads in flight per lane (written as one loop over both branches the pointer of the
+  // branch is itself fetched per iteration and every load waits for the one before: ~11 us of serial round trips per block)
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    const float* src = p.gate_w[br];
+    const int n4 = E * D / 4;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+      f32x4 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + 256 * j < n4) t[j] = *(const f32x4*)(src + 4 * (i0 + 256 * j));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + 256 * j < n4) *(f32x4*)(gw + br * E * D + 4 * (i0 + 256 * j)) = t[j];
+    }
   }
   if (threadIdx.x < 32) s_hist[threadIdx.x] = 0, s_usage[threadIdx.x] = 0.f, s_imp[threadIdx.x] = 0.f;
   __syncthreads();
-  const int l16 = threadIdx.x & 15;
-  const int64_t tpb = 16;  // tokens per block iteration
-  for (int64_t base = blockIdx.x * tpb; base < M; base += (int64_t)gridDim.x * tpb) {
+  for (int64_t base = blockIdx.x * tpb; base < M; base += stride) {
     const int64_t row = base + (threadIdx.x >> 4);
     const bool ok = row < M;
     const int64_t rc = ok ? row : M - 1;
+    if constexpr (NV > 8) load_x(base, vn);  // D = 1024: a second row set in flight costs the second wave per SIMD
     f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
-      v[c] = *(const f32x4*)(x + rc * D + 4 * (l16 + 16 * c));
+      v[c] = vn[c];
       s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
     }
+    // next iteration's rows, in flight during this one's arithmetic
+    if constexpr (NV <= 8)
+      if (base + stride < M) load_x(base + stride, vn);
     const float mean = group_sum<16>(s) / D;
     float q = 0.f;
 #pragma unroll
@@ -245,8 +304,10 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
                          v[c][3] * rstd * w[3] + b[3]};
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(h[0]), fabsf(h[1])), fmaxf(fabsf(h[2]), fabsf(h[3]))));
         if (ok && p.hn_bf16 != 3) {
-          if (p.hn_bf16) {
-            *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_h16(p.hn_bf16, h[0], h[1]), pack_h16(p.hn_bf16, h[2], h[3]));
+          if (p.hn_bf16 == 2) {  // (one uniform branch per chunk, not one per converted pair)
+            *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_h16(2, h[0], h[1]), pack_h16(2, h[2], h[3]));
+          } else if (p.hn_bf16) {
+            *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_h16(1, h[0], h[1]), pack_h16(1, h[2], h[3]));
           } else {
             *(f32x4*)((float*)p.hn + ((int64_t)br * M + row) * D + k) = h;
           }
@@ -699,6 +760,7 @@ int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1,
              const float* b2, void* y2, int y2_bf, hipStream_t s, int x_bf) {
   if (M <= 0) return MDM_OK;
   if (!x || !w1 || !b1 || (w2 && (!b2 || !y2)) || (!w2 && !y1)) return MDM_ERR_ARG;
+  if ((unsigned)x_bf > 2 || (unsigned)y1_bf > 2 || (unsigned)y2_bf > 2 || (x_bf | y1_bf | y2_bf) == 3) return MDM_ERR_ARG;  // one 16-bit format per launch
 #define CALL(NE, VEC) \
   hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid((M + 1) / 2)), dim3(256), 0, s, x, x_bf, M, D, w1, b1, y1, y1_bf, w2, b2, y2, y2_bf)
   MDM_ROW_DISPATCH(D, CALL);
@@ -711,6 +773,7 @@ int style_in(const float* x, int64_t M, int D, int S, const float* pw, const flo
              const float* sb, const float* sc, const int* pos4, int x_bf, void* out, int out_bf, hipStream_t s) {
   if (M <= 0) return MDM_OK;
   if (!x || !sw || !sb || !sc || !out || S <= 0) return MDM_ERR_ARG;
+  if ((unsigned)x_bf > 2 || (unsigned)out_bf > 2 || (x_bf | out_bf) == 3 || (pw && !pb)) return MDM_ERR_ARG;  // one 16-bit format per launch
 #define CALL(NE, VEC)                                                                                              \
   hipLaunchKernelGGL((style_in_kernel<NE, VEC>), dim3(row_grid(M)), dim3(256), 0, s, x, M, D, S, pw, pb, sw, sb, sc, \
                      pos4, x_bf, out, out_bf)
