@@ -102,11 +102,16 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
     for (int i = 0; i < 4; ++i) glds16(w + (int64_t)(16 * i) * g.ldw2, s + (wid * 4 + i) * 1024);
   };
 
+  // The accumulators START from the biases (b2 here, b1 at the top of every hidden chunk): those loads then complete under the
+  // wait the first K step has anyway.  Loaded where they are added -- after the MFMAs -- every one of them is a separate round
+  // trip behind the LDS-DMA queue (vmcnt is one in-order counter): 16 per tile in phase 1 and 64 in the epilogue.
   f32x4 y[4][8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < 8; ++j) {
+    const f32x4 bb = b2 ? *(const f32x4*)(b2 + wn * 128 + j * 16 + fq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) y[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) y[i][j] = bb;
+  }
 
   // One DMA stream through the 2-stage ring: per chunk, nkt phase-1 steps then 8 phase-2 steps; step st uses stage st & 1
   // and prefetches step st + 1 right after the barrier that retires step st - 1.
@@ -117,9 +122,11 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
       // ---- phase 1: h[128 x 256 chunk] = X (128 x Din) . W1 chunk (256 x Din)^T ; wave: rows wm*64.., units wn*64..
       f32x4 h[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 bb = b1 ? *(const f32x4*)(b1 + chunk * FC + wn * 64 + j * 16 + fq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) h[i][j] = bb;
+      }
       for (int kt = 0; kt < nkt; ++kt, ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -146,17 +153,16 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
           }
         }
       }
-      // bias + exact GELU -> bf16 hidden chunk in LDS.  Lane: row m = wm*64 + 16 i + frow, units f = wn*64 + 16 j + 4 fq + r.
+      // exact GELU (bias already in h) -> 16-bit hidden chunk in LDS.  Lane: row m = wm*64 + 16 i + frow, units f = wn*64 + 16 j + 4 fq + r.
       // (the previous chunk's phase-2 readers of hc are behind at least one barrier of the phase-1 loop)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int f = wn * 64 + j * 16 + fq * 4;
-        const f32x4 bb = b1 ? *(const f32x4*)(b1 + chunk * FC + f) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = wm * 64 + i * 16 + frow;
-          const f32x2 g01 = gelu_erf2((f32x2){h[i][j][0] + bb[0], h[i][j][1] + bb[1]});
-          const f32x2 g23 = gelu_erf2((f32x2){h[i][j][2] + bb[2], h[i][j][3] + bb[3]});
+          const f32x2 g01 = gelu_erf2((f32x2){h[i][j][0], h[i][j][1]});
+          const f32x2 g23 = gelu_erf2((f32x2){h[i][j][2], h[i][j][3]});
           const float v0 = g01[0], v1 = g01[1], v2 = g23[0], v3 = g23[1];
           // hidden chunk image: 512-B rows, 16-B chunk index (f >> 3) swizzled by (m & 15); 8-B half (f >> 2) & 1
           *(uint2*)(hc + m * 512 + (((f >> 3) ^ (m & 15)) << 4) + ((f >> 2) & 1) * 8) =
@@ -197,21 +203,29 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
   const float* __restrict__ R2 = g.R2;
 #pragma unroll 1
   for (int p = 0; p < 4; ++p) {
+    // this pass's two row scales, requested before the barrier (rows clamped, not predicated: no branch around the loads)
+    float rs2[2] = {1.f, 1.f};
+    if (g.rowscale) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int m = row0 + 32 * p + ii * 16 + frow;
+        rs2[ii] = g.rowscale[m < row_end ? m : row_end - 1];
+      }
+    }
     __syncthreads();
     if (wm == (p >> 1)) {
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
-        const int ml = ii * 16 + frow, m = row0 + 32 * p + ml;
-        const float rs = (g.rowscale && m < row_end) ? g.rowscale[m] : 1.f;
+        const int ml = ii * 16 + frow;
+        const float rs = rs2[ii];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int nn = wn * 128 + j * 16 + fq * 4;
-          const f32x4 bb = b2 ? *(const f32x4*)(b2 + nn) : (f32x4){0.f, 0.f, 0.f, 0.f};
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float a0 = y[ii][j][r], a1 = y[2 + ii][j][r];
-            v[r] = (((p & 1) ? a1 : a0) + bb[r]) * rs;
+            v[r] = ((p & 1) ? a1 : a0) * rs;
           }
           const int chunk = nn >> 2;  // 0..127
           *(f32x4*)(stg + ml * 512 + ((chunk ^ (ml & 31)) << 2)) = v;

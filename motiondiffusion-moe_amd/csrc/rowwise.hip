@@ -231,9 +231,11 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
                                                          MoeGateParams p) {
   constexpr int D = 64 * NV;  // (== D_rt: the host dispatches on D / 64) -- a compile-time row length folds the gate-row and
                               // output addresses into immediates
-  extern __shared__ __attribute__((aligned(16))) float gsm[];  // [2][E][D] gate weights, then counters
+  extern __shared__ __attribute__((aligned(16))) float gsm[];  // [2][E][D] gate weights, [2][D] LN weights, [2][D] LN biases, counters
   float* gw = gsm;
-  int* s_hist = (int*)(gsm + 2 * E * D);
+  float* lnw = gsm + 2 * E * D;  // from LDS, not from global memory: between the hn stores of two chunks a global load
+  float* lnb = lnw + 2 * D;      // cannot be moved up (the stores may alias it), so every chunk paid a round trip
+  int* s_hist = (int*)(lnb + 2 * D);
   float* s_usage = (float*)(s_hist + 32);
   float* s_imp = s_usage + 32;
   const int l16 = threadIdx.x & 15;
@@ -264,6 +266,12 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
       for (int j = 0; j < 4; ++j)
         if (i0 + 256 * j < n4) *(f32x4*)(gw + br * E * D + 4 * (i0 + 256 * j)) = t[j];
     }
+  }
+  for (int i = threadIdx.x; i < D / 4; i += 256) {
+    const f32x4 w0 = *(const f32x4*)(p.ln_w[0] + 4 * i), w1 = *(const f32x4*)(p.ln_w[1] + 4 * i);
+    const f32x4 b0 = *(const f32x4*)(p.ln_b[0] + 4 * i), b1 = *(const f32x4*)(p.ln_b[1] + 4 * i);
+    *(f32x4*)(lnw + 4 * i) = w0, *(f32x4*)(lnw + D + 4 * i) = w1;
+    *(f32x4*)(lnb + 4 * i) = b0, *(f32x4*)(lnb + D + 4 * i) = b1;
   }
   if (threadIdx.x < 32) s_hist[threadIdx.x] = 0, s_usage[threadIdx.x] = 0.f, s_imp[threadIdx.x] = 0.f;
   __syncthreads();
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
         const int k = 4 * (l16 + 16 * c);
-        const f32x4 w = *(const f32x4*)(p.ln_w[br] + k), b = *(const f32x4*)(p.ln_b[br] + k);
+        const f32x4 w = *(const f32x4*)(lnw + br * D + k), b = *(const f32x4*)(lnb + br * D + k);
         const f32x4 h = {v[c][0] * rstd * w[0] + b[0], v[c][1] * rstd * w[1] + b[1], v[c][2] * rstd * w[2] + b[2],
                          v[c][3] * rstd * w[3] + b[3]};
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(h[0]), fabsf(h[1])), fmaxf(fabsf(h[2]), fabsf(h[3]))));
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
           const int k = 4 * (l16 + 16 * c);
-          const f32x4 w = *(const f32x4*)(p.ln_w[br] + k), b = *(const f32x4*)(p.ln_b[br] + k);
+          const f32x4 w = *(const f32x4*)(lnw + br * D + k), b = *(const f32x4*)(lnb + br * D + k);
           uint32_t q = 0;
           q = __builtin_amdgcn_cvt_pk_fp8_f32((v[c][0] * rstd * w[0] + b[0]) * inv, (v[c][1] * rstd * w[1] + b[1]) * inv, q, false);
           q = __builtin_amdgcn_cvt_pk_fp8_f32((v[c][2] * rstd * w[2] + b[2]) * inv, (v[c][3] * rstd * w[3] + b[3]) * inv, q, true);
@@ -789,7 +797,7 @@ int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, i
   if (E < 2 || E > 16 || !x || !p.hn || !p.hist || !p.uimp || !p.top_idx || !p.top_val) return MDM_ERR_ARG;
   int nparts = 0;
   if (D % 64 == 0 && D <= 1024) {
-    const int smem = 2 * E * D * 4 + 3 * 32 * 4;
+    const int smem = 2 * E * D * 4 + 4 * D * 4 + 3 * 32 * 4;  // gate matrices, LayerNorm vectors, counters
     int64_t nb = (M + 15) / 16;
     const int grid = (int)(nb > 512 ? 512 : nb);  // measured end to end: 256 blocks -2 %, 1024 blocks -0.5 %
     nparts = grid;
