@@ -103,12 +103,43 @@ __global__ __launch_bounds__(NT3, 2) void gemm_x3_kernel(const GemmArgs g) {
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) stage(s, s);
 
+  // column / row constants of this lane's outputs, requested behind the first K tiles and long before the epilogue needs them
+  // (as gemm2.hip: loaded in the epilogue they were 8 + dependent round trips of dword loads per wave)
+  const int frow = lane & 15, fq = lane >> 4;
+  const float* __restrict__ bias = g.bias ? g.bias + offB : nullptr;
+  const float* __restrict__ colscale = g.colscale;
+  const int nbase = nt * BN3 + wn * 64 + fq * 4;
+  float bv[4][4], cv[4][4], rs[MI];
+  const bool vec_n = nt * BN3 + BN3 <= g.N && (!bias || ((((uintptr_t)bias) & 15) == 0 && (offB & 3) == 0)) &&
+                     (!colscale || (((uintptr_t)colscale) & 15) == 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (vec_n) {
+      const f32x4 b4 = bias ? *(const f32x4*)(bias + nbase + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 c4 = colscale ? *(const f32x4*)(colscale + nbase + j * 16) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = b4[r], cv[j][r] = g.out_scale * c4[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nbase + j * 16 + r;
+        const int nn = n < g.N ? n : g.N - 1;
+        bv[j][r] = bias ? bias[nn] : 0.f;
+        cv[j][r] = g.out_scale * (colscale ? colscale[nn] : 1.f);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = row0 + wm * (BM / 2) + i * 16 + frow;
+    rs[i] = (m < row_end && g.rowscale) ? g.rowscale[m] : 1.f;
+  }
+
   f32x4 acc[MI][4];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int younger = min(NSTAGE - 2, nk - 1 - kt);  // stages issued after this one that may stay in flight
     if (younger >= 2) {
@@ -155,31 +186,25 @@ __global__ __launch_bounds__(NT3, 2) void gemm_x3_kernel(const GemmArgs g) {
   // ---- epilogue (as gemm2.hip): registers -> LDS [BM][128] fp32 with bias / activation / scales, then whole rows out ------
   float* __restrict__ C = g.C;
   uint16_t* __restrict__ C16 = g.C16;
-  const float* __restrict__ bias = g.bias ? g.bias + offB : nullptr;
-  const float* __restrict__ colscale = g.colscale;
   const float* __restrict__ R1 = g.R1;
   const float* __restrict__ R2 = g.R2;
-  const int nbase = nt * BN3 + wn * 64 + fq * 4;
   __syncthreads();
   float* stg = (float*)smem;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int ml = wm * (BM / 2) + i * 16 + frow, m = row0 + ml;
-    const float rs = (m < row_end && g.rowscale) ? g.rowscale[m] : 1.f;
+    const int ml = wm * (BM / 2) + i * 16 + frow;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = nbase + j * 16 + r;
-        const int nn = n < g.N ? n : g.N - 1;
-        float x = g.alpha * (acc[i][j][r] + (bias ? bias[nn] : 0.f));
+        float x = g.alpha * (acc[i][j][r] + bv[j][r]);
         if constexpr (ACT == ACT_GELU) {
           x = gelu_erf(x);
         } else if constexpr (ACT == ACT_SILU) {
           x = silu(x);
         }
-        v[r] = x * (g.out_scale * (colscale ? colscale[nn] : 1.f) * rs);
+        v[r] = x * (cv[j][r] * rs[i]);
       }
       const int chunk = wn * 16 + j * 4 + fq;
       *(f32x4*)(stg + ml * 128 + ((chunk ^ (ml & 31)) << 2)) = v;
