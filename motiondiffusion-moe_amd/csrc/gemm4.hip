@@ -121,12 +121,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_256_kernel(const GemmArgs g) 
     cv[j] = g.colscale ? *(const f32x4*)(g.colscale + nbase + j * 16) : (f32x4){1.f, 1.f, 1.f, 1.f};
   }
   for (int p = 0; p < 4; ++p) {
+    // this slab's four row scales, requested together and before the barrier (rows clamped, not predicated: predicated they were
+    // four dependent round trips per slab; rows past row_end are never stored)
+    float rs4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (g.rowscale) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int m = row0 + 64 * p + ii * 16 + frow;
+        rs4[ii] = g.rowscale[m < row_end ? m : row_end - 1];
+      }
+    }
     __syncthreads();  // K loop / previous slab's readers done with the staging region
     if (wm == (p >> 1)) {
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
-        const int ml = ii * 16 + frow, m = row0 + 64 * p + ml;
-        const float rs = (g.rowscale && m < row_end) ? g.rowscale[m] : 1.f;
+        const int ml = ii * 16 + frow;
+        const float rs = rs4[ii];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4 v;
