@@ -95,6 +95,30 @@ def test_free_routing_flip_budget_bf16():
     assert flipped <= 1
 
 
+@pytest.mark.parametrize("precision", [2, 1])
+@pytest.mark.parametrize("B,S", [(2, 98), (3, 37), (1, 5)])
+def test_router_with_compile_time_expert_count_is_bit_identical(B, S, precision):
+    """At D = 512, E = 8 the 16-bit modes run the router instantiated for that expert count and format (straight-line
+    chunk loop, clamped instead of predicated hn stores); knob 27 selects the run-time-E kernel, knob 26 the constant one
+    wherever it exists.  Same arithmetic in the same order: the MoE block's outputs must be bit-equal, also where B * S is
+    not a multiple of the 16 tokens a workgroup iteration takes."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, 6, precision)
+    L = pkg("_lib")
+    out = _run_block(m, L.BLOCK_MOE, h, sc, length, xf)
+    outs = {}
+    for knob in (27, 26):
+        L.lib().mdm_set_gemm_variant(knob)
+        try:
+            outs[knob] = _run_block(m, L.BLOCK_MOE, h, sc, length, xf)
+        finally:
+            L.lib().mdm_set_gemm_variant(0)
+    ref = outs[27]
+    assert torch.equal(outs[26], ref), float((outs[26] - ref).abs().max())
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+
+
 @pytest.mark.parametrize("S,N,B", [(196, 28, 3), (98, 28, 2), (50, 9, 1), (12, 32, 2), (196, 85, 2), (98, 33, 2), (40, 64, 1), (77, 43, 2),
                                     (30, 128, 1)])
 def test_sd_fold_matches_unfolded_chain(S, N, B):
