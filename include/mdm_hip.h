@@ -380,7 +380,13 @@ int mdm_xattn_gate(const float* gate, const float* adaptive_gate, int32_t D, flo
 int mdm_fill_i64(int64_t* dst, int64_t n, const int32_t* src_dev, void* stream);
 int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
 
-/* tuning knob for benchmarks: selects the (BK, stages) variant of the bf16 throughput GEMM (0 = default) */
+/* Kernel-selection knob for same-box A/B runs and tests (0 = default; process-global, not thread-safe, never part of the data
+ * path).  Values: 1 / 2 force the 128- / 64-row tile of the 16-bit GEMM, 6 / 7 force / forbid its 256 x 256 tile, 28 two-stage
+ * ring in the 64-row tile; 21 expert MLP as two GEMMs instead of the fused kernel, 35 its second-generation kernel (41-44 that
+ * kernel's timing-only knock-outs); 22 unfolded text cross-attention, 24 folded at any pass count; 23 generic head_dim-256 paths;
+ * 25 fp32 instead of 16-bit intermediates; 26 / 27 router with compile-time / run-time expert count wherever both exist; 31
+ * input embedding in the mode's own precision; 36 fp32-grade Linears on the register-staged kernel, 37-39 ring depths of the
+ * LDS-DMA fp32-grade kernel. */
 int mdm_set_gemm_variant(int variant);
 /* diagnostic: s_memtime stamps of block 0 of the last bf16 GEMM launched with feat_S == -77 (host copy, synchronises) */
 int mdm_debug_stamps(uint64_t* out16);
