@@ -18,7 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import enum
 import math
-from typing import Callable, List, Optional
+from typing import Callable, Optional
 
 import numpy as np
 import torch

@@ -9,7 +9,7 @@ results do not depend on the world size and no rank ever materialises the global
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 import torch.distributed as dist

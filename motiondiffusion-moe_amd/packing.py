@@ -13,7 +13,6 @@ from typing import Dict, List, Tuple
 import torch
 
 from . import _lib as L
-from .synth import ephemeral_names, projection_names
 
 STYLE_SLOTS = ("local_style", "global_style", "cross_style", "ffn_style")
 

@@ -6,7 +6,6 @@ Host mirror of what the reference does on the CPU after sampling (tools/visualiz
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Optional
 
 import numpy as np

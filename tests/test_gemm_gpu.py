@@ -1,6 +1,5 @@
 """GPU: the fused MFMA GEMM (csrc/gemm.hip) through the C ABI against a torch fp64 reference."""
 import ctypes as C
-import math
 
 import pytest
 import torch

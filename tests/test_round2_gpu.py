@@ -6,12 +6,11 @@ import os
 import sys
 import types
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import ROOT, build_module, golden_state, load_golden, pkg, rel_inf
+from conftest import ROOT, build_module, load_golden, pkg, rel_inf
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import denoiser_ref as R  # noqa: E402

@@ -1,6 +1,6 @@
 """A/B of the GEMM tile variants on the big model's shapes (16-bit operands, fp32 + 16-bit outputs, GELU epilogue,
 graph-timed): knob 7 = 128^2 tiles only, 6 = the 256^2 tile wherever eligible."""
-import importlib, sys, os
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
