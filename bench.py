@@ -393,7 +393,8 @@ def main():
         done[0] = 0
         r.t_dev.fill_(a.schedule - 1)
         live = probe_dominant_kernel(r, m) if not r.chunks else None  # single-stream steps only
-        modes = None if (a.no_modes or a.sampler != "cfg" or a.config != "small") else mode_table(a, m, inputs, host, diff, kw, dev, a.precision, ms)
+        # (the per-mode table is a single-GPU report: a scaling run keeps rank 0 no longer than the other ranks)
+        modes = None if (a.no_modes or world > 1 or a.sampler != "cfg" or a.config != "small") else mode_table(a, m, inputs, host, diff, kw, dev, a.precision, ms)
         traffic = None  # HBM-side bytes per step from the committed PMC passes (same workload only)
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(pmc) and (a.config, B, T, a.precision, a.sampler) == ("small", 32, 196, 2, "cfg"):
