@@ -412,6 +412,9 @@ def main():
             "config": {"workload": workload,
                        "global_batch": B * world, "parallelism": f"batch-shard x{world}, weights replicated"},
             "sample_steps_per_s": round(steps_per_s * B * world, 1),
+            # SURVEY 8(d) asks for ms per model forward as well: a CFG step is two B-row forwards (run here as ONE 2B-row launch
+            # sequence) plus the guidance / posterior update, a DDIM step is one
+            "ms_per_forward": round(ms / nfwd, 3),
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK[a.precision] / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.precision], 4), "traffic": traffic,
                          "traffic_note": "fabric bytes per step from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, "
