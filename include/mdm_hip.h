@@ -124,13 +124,20 @@ typedef struct MdmMlpDesc {
   uint16_t* C16; /* optional 16-bit copy */
   int64_t ldc;
   int32_t h16;   /* MDM_H16_*: format of X, w1, w2 and C16 (0 = bf16) */
-  /* optional fragment-major copies of w1 / w2 (same 16-bit format, built by packing.py: mlp_fragment_major): when both
-   * are set and Din == Dout == 512 the second-generation kernel (csrc/mlp2.hip) runs; group stride F*Din / Dout*F elements */
-  const uint16_t* w1f;
-  const uint16_t* w2f;
+  /* optional weight STREAM built by mdm_mlp_stream_pack from the same w1 / w2 (same 16-bit format): per (group, wave) one
+   * linear run of 1-KiB MFMA fragments in consumption order (csrc/mlp_stream.hip).  When set and Dout == 512,
+   * Din % 128 == 0, F % 256 == 0 the streamed-weight kernel runs and w1 / w2 are not read; wstream_gs = elements per
+   * group = F * Din + Dout * F.  The buffer must have mdm_mlp_stream_elems() elements (8 KiB of tail padding). */
+  const uint16_t* wstream;
+  int64_t wstream_gs;
 } MdmMlpDesc;
 
 int mdm_fused_mlp(const MdmMlpDesc* desc, void* stream);
+/* Weight stream of the fused MLP: elements the buffer needs, and the packer (fp32 row-major w1 [G, F, Din], w2 [G, Dout, F]
+ * -> h16-format stream; once at load time). */
+int64_t mdm_mlp_stream_elems(int32_t G, int32_t F, int32_t Din, int32_t Dout);
+int mdm_mlp_stream_pack(const float* w1, const float* w2, int32_t G, int32_t F, int32_t Din, int32_t Dout, int32_t h16,
+                        uint16_t* out, void* stream);
 
 /* fp32 [rows, K] (row stride ld_src) -> bf16 planes [rows, Kpad] (Kpad = ld_dst, multiple of 32, zero padded);
  * lo may be NULL.  Weight packing happens once at load time (not on the hot path). */
@@ -181,7 +188,8 @@ typedef struct MdmLayer { /* MoEExtendedDecoderLayer, transformer.py:17-64 */
   const float *moe_ln_w[2], *moe_ln_b[2], *gate_w[2], *gate_b[2];
   MdmPacked w1; /* [2*E*F, D] */
   MdmPacked w2; /* [2*E*D, F] */
-  const uint16_t *w1f, *w2f; /* optional fragment-major copies for csrc/mlp2.hip (16-bit expert modes, D == 512), or NULL */
+  const uint16_t* wstream;   /* optional weight stream of the 2E expert MLPs (mdm_mlp_stream_pack; 16-bit expert modes), or NULL */
+  int64_t wstream_gs;        /* elements per expert group: F * D + D * F */
   const float *b1, *b2;
   float *usage[2], *importance[2]; /* expert_usage / expert_importance buffers, updated in place; may be NULL */
   MdmStyle ffn_style;

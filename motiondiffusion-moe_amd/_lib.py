@@ -57,7 +57,7 @@ class MlpDesc(C.Structure):
                 ("w2", C.c_void_p), ("ldw2", C.c_int64), ("w2_gs", C.c_int64), ("b2", C.c_void_p), ("b2_gs", C.c_int64),
                 ("rowscale", C.c_void_p), ("R1", C.c_void_p), ("ldr1", C.c_int64), ("r1_scale", C.c_float),
                 ("R2", C.c_void_p), ("ldr2", C.c_int64), ("C", C.c_void_p), ("C16", C.c_void_p), ("ldc", C.c_int64),
-                ("h16", C.c_int32), ("w1f", C.c_void_p), ("w2f", C.c_void_p)]
+                ("h16", C.c_int32), ("wstream", C.c_void_p), ("wstream_gs", C.c_int64)]
 
 
 class Packed(C.Structure):
@@ -87,7 +87,7 @@ class Layer(C.Structure):
                 ("ca_q_b", C.c_void_p), ("ca_k_b", C.c_void_p), ("ca_v_b", C.c_void_p), ("ca_gvec", C.c_void_p),
                 ("ca_style", Style),
                 ("moe_ln_w", _P2), ("moe_ln_b", _P2), ("gate_w", _P2), ("gate_b", _P2), ("w1", Packed), ("w2", Packed),
-                ("w1f", C.c_void_p), ("w2f", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p), ("usage", _P2), ("importance", _P2), ("ffn_style", Style),
+                ("wstream", C.c_void_p), ("wstream_gs", C.c_int64), ("b1", C.c_void_p), ("b2", C.c_void_p), ("usage", _P2), ("importance", _P2), ("ffn_style", Style),
                 ("sd_q", Packed), ("sd_k", Packed), ("sd_v", Packed), ("sd_out", Packed), ("sd_f1", Packed),
                 ("sd_f2", Packed), ("sd_q_b", C.c_void_p), ("sd_k_b", C.c_void_p), ("sd_v_b", C.c_void_p),
                 ("sd_out_b", C.c_void_p), ("sd_ln_w", C.c_void_p), ("sd_ln_b", C.c_void_p), ("sd_f1_b", C.c_void_p),
@@ -130,7 +130,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mdm_version.restype = C.c_char_p
         for name in EXPORTS:
-            if name in ("mdm_workspace_bytes", "mdm_text_head_workspace_bytes", "mdm_moe_train_workspace_bytes"):
+            if name in ("mdm_workspace_bytes", "mdm_text_head_workspace_bytes", "mdm_moe_train_workspace_bytes", "mdm_mlp_stream_elems"):
                 getattr(L, name).restype = C.c_int64
             elif name != "mdm_version":
                 getattr(L, name).restype = C.c_int
@@ -139,7 +139,7 @@ def lib():
 
 
 # every symbol include/mdm_hip.h declares (checked by tests/test_abi.py)
-EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_pack_bf16", "mdm_pack_f16", "mdm_pack_fp8", "mdm_workspace_bytes", "mdm_text_cache_build",
+EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_mlp_stream_elems", "mdm_mlp_stream_pack", "mdm_pack_bf16", "mdm_pack_f16", "mdm_pack_fp8", "mdm_workspace_bytes", "mdm_text_cache_build",
            "mdm_denoiser_forward", "mdm_stem_cache_build", "mdm_block_forward", "mdm_moe_ffn_forward", "mdm_dual_self_attn_forward", "mdm_linear_xattn_forward",
            "mdm_softmax_xattn_ffn_forward", "mdm_performer_attn_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
            "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_noise_normal", "mdm_noise_normal_ids", "mdm_text_head_workspace_bytes", "mdm_text_head_forward", "mdm_motion_postprocess", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant", "mdm_debug_stamps", "mdm_probe_enable", "mdm_probe_read", "mdm_route_dump",

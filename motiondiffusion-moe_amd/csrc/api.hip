@@ -58,6 +58,13 @@ int mdm_fused_mlp(const MdmMlpDesc* d, void* stream) {
   return mdm::fused_mlp(*d, (hipStream_t)stream);
 }
 
+int64_t mdm_mlp_stream_elems(int32_t G, int32_t F, int32_t Din, int32_t Dout) { return mdm::mlp_stream_elems(G, F, Din, Dout); }
+
+int mdm_mlp_stream_pack(const float* w1, const float* w2, int32_t G, int32_t F, int32_t Din, int32_t Dout, int32_t h16,
+                        uint16_t* out, void* stream) {
+  return mdm::mlp_stream_pack(w1, w2, G, F, Din, Dout, h16, out, (hipStream_t)stream);
+}
+
 int mdm_pack_bf16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* hi, uint16_t* lo,
                   int64_t ld_dst, void* stream) {
   if (!src || !hi || rows < 0 || K <= 0 || ld_dst < K || (ld_dst & 31)) return MDM_ERR_ARG;

@@ -60,7 +60,10 @@ bool gemm_x3_dma_eligible(const GemmArgs& a);
 int gemm_x3_dma(const GemmArgs& a, hipStream_t stream);  // gemm3.hip: bf16x3 with LDS-DMA staged fp32 activations
 bool gemm_fp8_eligible(const GemmArgs& a);
 int gemm_fp8(const GemmArgs& a, hipStream_t stream);  // gemm8.hip: e4m3 operands, block-scaled MFMA K = 128
-bool fused_mlp2_supported(const MdmMlpDesc& a);
-int fused_mlp2(const MdmMlpDesc& a, hipStream_t stream);  // mlp2.hip: hidden layer kept in REGISTERS (Din = Dout = 512)
+// mlp_stream.hip: the same MLP with the weights streamed global -> registers from a packed fragment stream
+bool fused_mlp_stream_supported(const MdmMlpDesc& a);
+int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream);
+int64_t mlp_stream_elems(int G, int F, int Din, int Dout);
+int mlp_stream_pack(const float* w1, const float* w2, int G, int F, int Din, int Dout, int h16, uint16_t* out, hipStream_t stream);
 
 }  // namespace mdm

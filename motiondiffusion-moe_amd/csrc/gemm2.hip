@@ -333,7 +333,7 @@ bool gemm_bf16_eligible(const GemmArgs& a) {
 template <typename HT, int BM, int BK, int NS, int ACT>
 static int launch_bf16_act(const GemmArgs& a, hipStream_t stream) {
   constexpr int smem = NS * (BM + BN) * 2 * BK;
-  static bool attr_set = false;
+  static DevOnce attr_set;
   if (smem > 65536 && !attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<HT, BM, BK, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess)

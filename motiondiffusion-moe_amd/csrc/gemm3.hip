@@ -246,7 +246,7 @@ template <int BM, int NS, int ACT>
 int launch3_act(const GemmArgs& a, hipStream_t stream) {
   constexpr int ring = NS * (BM * 128 + 2 * BN3 * 64), stgb = BM * 128 * 4;
   constexpr int smem = ring > stgb ? ring : stgb;
-  static bool attr = false;
+  static DevOnce attr;
   if (smem > 65536 && !attr) {
     if (hipFuncSetAttribute((const void*)gemm_x3_kernel<BM, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_256_kernel(const GemmArgs g) 
 template <typename HT, int ACT>
 int launch256(const GemmArgs& a, hipStream_t stream) {
   constexpr int smem = 2 * STAGE_B;  // 128 KiB
-  static bool attr = false;
+  static DevOnce attr;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<HT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
         hipSuccess)

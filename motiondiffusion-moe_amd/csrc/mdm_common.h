@@ -14,6 +14,30 @@ namespace mdm {
     if (e__ != hipSuccess) return (int)MDM_ERR_LAUNCH; \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only, so the "already set" state of a launcher
+// is kept per device ordinal: a process that drives a second GPU sets the attribute there too.  DevOnce replaces a
+// `static bool`, DevInt a `static int` (largest size set so far) in the launchers; both read hipGetDevice() per use.
+inline int dev_ordinal() {
+  int d = 0;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0;
+}
+struct DevOnce {
+  unsigned long long mask = 0;
+  bool operator!() const { return !((mask >> dev_ordinal()) & 1ull); }
+  DevOnce& operator=(bool v) {
+    if (v) mask |= 1ull << dev_ordinal();
+    return *this;
+  }
+};
+struct DevInt {
+  int v[64] = {};
+  operator int() const { return v[dev_ordinal()]; }
+  DevInt& operator=(int x) {
+    v[dev_ordinal()] = x;
+    return *this;
+  }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));  // MFMA A/B fragment: 8 bf16 in 4 VGPRs

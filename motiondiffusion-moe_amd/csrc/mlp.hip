@@ -255,6 +255,8 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_kernel(const MdmMlpDesc g) {
 }  // namespace
 
 bool fused_mlp_supported(const MdmMlpDesc& a) {
+  if (fused_mlp_stream_supported(a)) return true;
+  if (!a.w1 || !a.w2) return false;
   if (a.Dout != DOUT || a.Din < 64 || (a.Din % 64) || a.F < FC || (a.F % FC) || a.M < 1) return false;
   if ((a.ldx % 8) || (a.ldw1 % 8) || (a.ldw2 % 8) || (a.w1_gs % 8) || (a.w2_gs % 8)) return false;
   if (((((uintptr_t)a.X) | ((uintptr_t)a.w1) | ((uintptr_t)a.w2)) & 15)) return false;
@@ -266,13 +268,15 @@ bool fused_mlp_supported(const MdmMlpDesc& a) {
 extern int g_bf16_variant;
 
 int fused_mlp(const MdmMlpDesc& a, hipStream_t stream) {
-  // The second generation (hidden layer in registers, csrc/mlp2.hip) is correct but measured SLOWER than this kernel (215 vs
-  // 179 us at 50176 rows; knock-outs in DESIGN.md section 6): it runs only on request (knob 35, or 41..44 for its knock-outs)
-  if ((g_bf16_variant == 35 || (g_bf16_variant >= 41 && g_bf16_variant <= 44)) && fused_mlp2_supported(a)) return fused_mlp2(a, stream);
+  // streamed-weight kernel (csrc/mlp_stream.hip) whenever the caller packed a weight stream and the shape fits; knob 34
+  // keeps this kernel for A/B runs
+  if (g_bf16_variant != 34 && fused_mlp_stream_supported(a)) return fused_mlp_stream(a, stream);
   if (!a.X || !a.w1 || !a.w2 || (!a.C && !a.C16)) return MDM_ERR_ARG;
-  if (!fused_mlp_supported(a)) return MDM_ERR_UNSUPPORTED;
+  MdmMlpDesc plain = a;
+  plain.wstream = nullptr;
+  if (!fused_mlp_supported(plain)) return MDM_ERR_UNSUPPORTED;
   constexpr int smem = HC_B + NST * STAGE_B;  // 163840
-  static bool attr = false;
+  static DevOnce attr;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)fused_mlp_kernel<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
         hipFuncSetAttribute((const void*)fused_mlp_kernel<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)

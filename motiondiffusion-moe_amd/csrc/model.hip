@@ -346,7 +346,7 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
   f.rowscale = w.rowscale, f.r1_scale = 1.f;
   f.C = w.y2, f.ldc = D;
   f.h16 = c.h16;
-  f.w1f = l.w1f, f.w2f = l.w2f;
+  f.wstream = l.wstream, f.wstream_gs = l.wstream_gs;
   const bool h = c.bf || c.mix;  // 16-bit expert operands
   if (c.fp8) {
     // fp8 experts (switch_moe.py:19-25,104-109 on e4m3 operands): hidden = e4m3(8 * GELU(dequant(X8 W1_8^T) + b1)), then

@@ -549,7 +549,7 @@ int launch_gate_ln_one(int D, int E, int grid, hipStream_t s, const float* x, co
                        const int* pos4, const int* top_idx, const float* ln_w, const float* ln_b, const float* gate_w,
                        const float* gate_b, int64_t M, float* dlogits, float* dx, float* g_ln_w, float* g_ln_b) {
   const int smem = (2 * E * D + 4 * D) * 4;
-  static int attr = 0;
+  static DevInt attr;
   if (smem > 65536 && smem > attr) {
     if (hipFuncSetAttribute((const void*)gate_ln_bwd_kernel<NE, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;

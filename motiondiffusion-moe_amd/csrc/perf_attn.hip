@@ -312,7 +312,7 @@ int perf_attn(const void* qkv, int h16, const uint16_t* PT, int ldp, const float
   const int TP = (S + 31) & ~31, TS = TP + 8;
   const int vreg = (DH * TS > MF * PS) ? DH * TS : MF * PS;
   const int smem = (MF * TS + vreg + DH * PS) * 2;
-  static int attr = 0;
+  static DevInt attr;
   if (smem > attr) {
     if (hipFuncSetAttribute((const void*)perf_attn_kernel<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
         hipFuncSetAttribute((const void*)perf_attn_kernel<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)

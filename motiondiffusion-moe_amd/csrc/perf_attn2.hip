@@ -360,7 +360,7 @@ inline int64_t up256(int64_t n) { return (n + 255) & ~(int64_t)255; }
 template <typename HT>
 int launch256(const uint16_t* qkv, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B, int S,
               int H, uint16_t* out, uint8_t* scratch, hipStream_t s) {
-  static bool attr = false;
+  static DevOnce attr;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)perf_feat256_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_PA2) != hipSuccess ||
         hipFuncSetAttribute((const void*)perf_kvnum256_kernel<HT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_PA2) != hipSuccess ||

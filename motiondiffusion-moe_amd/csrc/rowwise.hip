@@ -816,7 +816,7 @@ bool gate16_const_wanted(int nv, int E) {
 }
 template <int NV, int EX, int HNF>
 bool launch_gate16_const(int grid, int smem, hipStream_t s, const float* x, int64_t M, int D, int E, const MoeGateParams& p) {
-  static int attr_done = 0;
+  static DevInt attr_done;
   if (smem > 65536 && smem > attr_done) {
     if (hipFuncSetAttribute((const void*)moe_gate16_kernel<NV, true, EX, HNF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return false;
@@ -851,7 +851,7 @@ int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, i
     int64_t nb = (M + 15) / 16;
     const int grid = (int)(nb > 512 ? 512 : nb);  // measured end to end: 256 blocks -2 %, 1024 blocks -0.5 %
     nparts = grid;
-    static int attr_done = 0;
+    static DevInt attr_done;
     if (smem > 65536 && smem > attr_done) {
       const void* fns[4] = {(const void*)moe_gate16_kernel<16, true>, (const void*)moe_gate16_kernel<16, false>,
                             (const void*)moe_gate16_kernel<8, true>, (const void*)moe_gate16_kernel<8, false>};

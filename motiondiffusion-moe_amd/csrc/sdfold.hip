@@ -303,7 +303,7 @@ int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const u
             int h16, hipStream_t s) {
   if (!sd_fold_supported(D, H, N)) return MDM_ERR_UNSUPPORTED;
   if (!x16 || !kfold || !cb || !vfold || !bout || !ln_w || !ln_b || !out32 || !out16 || B <= 0 || S <= 0) return MDM_ERR_ARG;
-  static bool attr = false;
+  static DevOnce attr;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)sd_fold_kernel<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B) != hipSuccess ||
         hipFuncSetAttribute((const void*)sd_fold_kernel<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B) != hipSuccess)

@@ -288,7 +288,7 @@ template <typename HT, int NT32, bool IN16, int DHT>
 int launch_sd(const void* q, const float* kc, const float* vc, int B, int S, int H, int N, uint16_t* out16, float* out32,
               hipStream_t s) {
   constexpr int smem = (NT32 * 32 * (DHT + 8) + DHT * NS) * 2;
-  static bool attr = false;
+  static DevOnce attr;
   if (smem > 65536 && !attr) {
     if (hipFuncSetAttribute((const void*)sd_attn_kernel<HT, NT32, IN16, DHT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
@@ -329,7 +329,7 @@ int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, 
   const dim3 grid(B * H), block(XNT);
   if (dh == DH2) {
     constexpr int smem = DH2 * PS2 * 2;
-    static bool attr = false;
+    static DevOnce attr;
     if (!attr) {
       if (hipFuncSetAttribute((const void*)lin_xattn256_kernel<HF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
           hipFuncSetAttribute((const void*)lin_xattn256_kernel<HF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||

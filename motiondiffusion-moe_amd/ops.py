@@ -160,26 +160,47 @@ def gemm_fp8(a8: torch.Tensor, a_scale: Optional[torch.Tensor], w: PackedWeight,
     return out if out is not None else out8
 
 
-def mlp_fragment_major(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype):
-    """Fragment-major 16-bit copies of expert weights for csrc/mlp2.hip (Din = Dout = 512, F % 64 == 0):
-    w1 (G, F, D) -> [G][chunk c = F/32][k-step s = D/16][lane = 32 h + r][8]   with element  w1[g][32c + r][16s + 8h + j];
-    w2 (G, Dout, F) -> [G][chunk c][n-tile t = Dout/32][k-step s2 < 2][lane = 32 h + r][8]   with element
-    w2[g][32t + r][32c + 16 s2 + 8 (j >> 2) + 4 h + (j & 3)]: the k order inside a fragment follows the register -> row
-    map of a 32x32 MFMA accumulator, so the GELU'd hidden tile feeds phase 2 without leaving registers.
-    Every 1-KiB run is one MFMA A-fragment of one wave: what one LDS-DMA instruction moves."""
-    G, F, D = w1.shape
+def mlp_stream_pack(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Weight stream of the streamed-weight fused MLP (csrc/mlp_stream.hip, include/mdm_hip.h mdm_mlp_stream_pack):
+    fp32 w1 (G, F, Din) / w2 (G, Dout, F) (or without the group axis) -> one 16-bit buffer holding, per (group, wave), the
+    1-KiB MFMA fragments of both layers in the order the wave consumes them (+ 8 KiB of tail padding)."""
+    L.require_cuda(w1, w2)
+    if w1.dim() == 2:
+        w1, w2 = w1[None], w2[None]
+    G, F, Din = w1.shape
     Dout = w2.shape[1]
-    assert w2.shape == (G, Dout, F) and F % 32 == 0 and D % 16 == 0 and Dout % 32 == 0
-    a = w1.reshape(G, F // 32, 32, D // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)            # g, c, s, h, r, j
-    b = w2.reshape(G, Dout // 32, 32, F // 32, 2, 2, 2, 4).permute(0, 3, 1, 4, 6, 2, 5, 7)  # g, c, t, s2, h, r, q, i
-    return a.to(dtype).contiguous().reshape(G, F * D), b.to(dtype).contiguous().reshape(G, Dout * F)
+    assert w2.shape == (G, Dout, F) and dtype in (torch.float16, torch.bfloat16)
+    w1 = w1.detach().to(torch.float32).contiguous()
+    w2 = w2.detach().to(torch.float32).contiguous()
+    n = L.lib().mdm_mlp_stream_elems(C.c_int32(G), C.c_int32(F), C.c_int32(Din), C.c_int32(Dout))
+    out = torch.empty(n, dtype=dtype, device=w1.device)
+    with torch.cuda.device(w1.device):
+        L.check(L.lib().mdm_mlp_stream_pack(C.c_void_p(w1.data_ptr()), C.c_void_p(w2.data_ptr()), C.c_int32(G), C.c_int32(F),
+                                            C.c_int32(Din), C.c_int32(Dout),
+                                            C.c_int32(L.H16_F16 if dtype == torch.float16 else L.H16_BF16),
+                                            C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr())), "mdm_mlp_stream_pack")
+    return out
+
+
+def mlp_stream_pack_reference(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """The same layout written as torch reshapes (tests check the packer kernel against it)."""
+    if w1.dim() == 2:
+        w1, w2 = w1[None], w2[None]
+    G, F, Din = w1.shape
+    Dout = w2.shape[1]
+    NJ, Cn, KT = Dout // 128, F // 256, Din // 32
+    a = w1.reshape(G, Cn, 8, 2, 16, KT, 4, 8).permute(0, 2, 1, 5, 3, 6, 4, 7)      # g, w, c, step, j, q, r, e
+    b = w2.reshape(G, 8, NJ, 16, Cn, 8, 4, 8).permute(0, 1, 4, 5, 2, 6, 3, 7)      # g, w, c, s, j, q, r, e
+    s = torch.cat([a.reshape(G, 8, Cn, -1), b.reshape(G, 8, Cn, -1)], dim=3).to(dtype).reshape(-1)
+    return torch.cat([s, torch.zeros(8 * 512, dtype=dtype, device=s.device)])
 
 
 def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w2: PackedWeight,
               b2: Optional[torch.Tensor], *, gather=None, goff=None, rowscale=None, r1=None, r1_scale: float = 1.0,
               r2=None, rows: Optional[int] = None, out: Optional[torch.Tensor] = None,
-              out16: Optional[torch.Tensor] = None, frag=None) -> torch.Tensor:
-    """y = (GELU(x w1^T + b1) w2^T + b2) * rowscale + r1_scale * r1 + r2 with the hidden layer kept on chip (mlp.hip).
+              out16: Optional[torch.Tensor] = None, wstream: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = (GELU(x w1^T + b1) w2^T + b2) * rowscale + r1_scale * r1 + r2 with the hidden layer kept on chip (mlp.hip;
+    mlp_stream.hip when ``wstream`` is given).
     ``goff`` (int32 [G+1], device) selects grouped mode: w1 / w2 / b1 / b2 then carry a leading group axis."""
     L.require_cuda(x16)
     assert x16.dtype in (torch.bfloat16, torch.float16) and x16.stride(-1) == 1
@@ -201,9 +222,9 @@ def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w
     d.w1, d.ldw1, d.b1 = w1.hi.data_ptr(), w1.Kp, L.ptr(b1)
     d.w2, d.ldw2, d.b2 = w2.hi.data_ptr(), w2.Kp, L.ptr(b2)
     d.rowscale = L.ptr(rowscale)
-    if frag is not None:  # (w1f, w2f) from mlp_fragment_major: selects the second-generation kernel when the shape fits
-        assert frag[0].dtype == x16.dtype and frag[1].dtype == x16.dtype
-        d.w1f, d.w2f = frag[0].data_ptr(), frag[1].data_ptr()
+    if wstream is not None:  # from mlp_stream_pack: selects the streamed-weight kernel when the shape fits
+        assert wstream.dtype == x16.dtype
+        d.wstream, d.wstream_gs = wstream.data_ptr(), F * w1.K + Dout * F
     d.r1_scale = r1_scale
     if r1 is not None:
         d.R1, d.ldr1 = r1.data_ptr(), r1.stride(0)

@@ -167,19 +167,20 @@ class PackedModel:
                 else:
                     self.V[k[2:]] = t
             D, L_ = cfg["latent_dim"], cfg["num_layers"]
-            # fragment-major copies of the expert weights for the second-generation fused MLP (csrc/mlp2.hip; opt-in: it
-            # measured slower than the first generation): MDM_MLP_GEN2=1 + kernel knob 35
-            self.frag_major = {}
+            # weight streams of the expert MLPs for the streamed-weight fused kernel (csrc/mlp_stream.hip): the 16-bit
+            # modes at the shapes it takes; MDM_MLP_STREAM=0 keeps the LDS-staged kernel (A/B runs)
+            self.wstream = {}
             E2, F_ = 2 * cfg["moe_num_experts"], cfg["ff_size"]
             import os
-            if os.environ.get("MDM_MLP_GEN2") and D == 512 and F_ % 64 == 0 and precision in (L.PREC_BF16, L.PREC_F16, L.PREC_MIXED):
-                from .ops import mlp_fragment_major
+            if (os.environ.get("MDM_MLP_STREAM", "1") != "0" and D == 512 and F_ % 256 == 0
+                    and precision in (L.PREC_BF16, L.PREC_F16, L.PREC_MIXED)):
+                from .ops import mlp_stream_pack
                 for li in range(2 * L_):
                     k = f"L{li}."
                     fmt = weight_format(k + "w1", precision, head_dim)
                     dt = torch.float16 if fmt == "f16" else torch.bfloat16
-                    self.frag_major[k] = mlp_fragment_major(lay["W:" + k + "w1"].to(dev).reshape(E2, F_, D),
-                                                            lay["W:" + k + "w2"].to(dev).reshape(E2, D, F_), dt)
+                    self.wstream[k] = mlp_stream_pack(lay["W:" + k + "w1"].to(dev).reshape(E2, F_, D),
+                                                      lay["W:" + k + "w2"].to(dev).reshape(E2, D, F_), dt)
             self.layers = (L.Layer * (2 * L_))()
             for li, (pre, tag) in enumerate(layer_tags(L_)):
                 self._fill_layer(self.layers[li], f"L{li}.", pre, counters)
@@ -246,9 +247,9 @@ class PackedModel:
                 l.importance[b] = counters[br + ".expert_importance"].data_ptr()
         l.w1, l.b1 = self._packed(k + "w1"), V[k + "b1"].data_ptr()
         l.w2, l.b2 = self._packed(k + "w2"), V[k + "b2"].data_ptr()
-        fm = self.frag_major.get(k)
-        if fm is not None:
-            l.w1f, l.w2f = fm[0].data_ptr(), fm[1].data_ptr()
+        ws = self.wstream.get(k)
+        if ws is not None:
+            l.wstream, l.wstream_gs = ws.data_ptr(), 2 * D * self.cfg["ff_size"]
         self._style(l.ffn_style, k + "ffn_style.")
         l.sd_ln_w, l.sd_ln_b = V[k + "sd_ln_w"].data_ptr(), V[k + "sd_ln_b"].data_ptr()
 

@@ -79,14 +79,25 @@ def test_unsupported_shapes_are_refused():
         ops.fused_mlp(x16, pw1, None, pw2, None)  # Din % 64 != 0
 
 
+def test_weight_stream_packer_matches_the_documented_layout():
+    """mdm_mlp_stream_pack (device kernel) against the same layout written as torch reshapes (ops.mlp_stream_pack_reference)."""
+    ops = pkg("ops")
+    for G, F, Din, Dout, dt in [(3, 512, 128, 512, torch.bfloat16), (2, 1024, 512, 512, torch.float16)]:
+        w1, w2 = _rand(G, F, Din, seed=31), _rand(G, Dout, F, seed=32)
+        got = ops.mlp_stream_pack(w1, w2, dt)
+        want = ops.mlp_stream_pack_reference(w1, w2, dt)
+        assert got.shape == want.shape and torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("sizes,F", [([130, 0, 257, 1, 128], 1024), ([3136] * 4, 1024), ([64, 700], 256)])
-def test_gen2_registers_resident_hidden_layer(dtype, sizes, F):
-    """Second-generation fused expert MLP (csrc/mlp2.hip: hidden layer kept in registers, fragment-major weight stream):
-    grouped / gathered / ragged / empty groups, both 16-bit formats, fp32 and 16-bit outputs, against the fp64 reference
-    with the same operand rounding, and against the first-generation kernel (knob 34) on the same inputs."""
+@pytest.mark.parametrize("sizes,F,Din", [([130, 0, 257, 1, 128], 1024, 512), ([3136] * 4, 1024, 512), ([64, 700], 256, 128),
+                                         ([113, 111, 112, 225, 17], 512, 256)])
+def test_streamed_weight_kernel(dtype, sizes, F, Din):
+    """Streamed-weight fused expert MLP (csrc/mlp_stream.hip: weights global -> registers from the packed fragment stream,
+    balanced tiles): grouped / gathered / ragged / empty groups, both 16-bit formats, fp32 and 16-bit outputs, against the
+    fp64 reference with the same operand rounding, and against the LDS-staged kernel (knob 34) on the same inputs."""
     L, ops = pkg("_lib"), pkg("ops")
-    Din, Dout, G, S = 512, 512, len(sizes), 900
+    Dout, G, S = 512, len(sizes), 900
     fmt = "f16" if dtype == torch.float16 else "bf16"
     M = sum(sizes)
     goff = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
@@ -97,14 +108,10 @@ def test_gen2_registers_resident_hidden_layer(dtype, sizes, F):
     w2, b2 = _rand(G, Dout, F, seed=25, scale=F ** -0.5), _rand(G, Dout, seed=26, scale=0.1)
     rs = _rand(M, seed=27).abs()
     pw1, pw2 = ops.PackedWeight(w1, fmt=fmt), ops.PackedWeight(w2, fmt=fmt)
-    frag = ops.mlp_fragment_major(w1, w2, dtype)
+    ws = ops.mlp_stream_pack(w1, w2, dtype)
     out = torch.full((M + 3, Dout), 7.0, device="cuda")
     out16 = torch.zeros((M + 3, Dout), dtype=dtype, device="cuda")
-    L.lib().mdm_set_gemm_variant(35)  # gen2 is opt-in (measured slower than gen1: DESIGN.md section 6)
-    try:
-        ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out=out, out16=out16, frag=frag)
-    finally:
-        L.lib().mdm_set_gemm_variant(0)
+    ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out=out, out16=out16, wstream=ws)
     x = src[gather.long()]
 
     def rd(t):
@@ -118,11 +125,37 @@ def test_gen2_registers_resident_hidden_layer(dtype, sizes, F):
         o += n
     e32 = rel_inf(out[:M].cpu(), ref.float().cpu())
     e16 = rel_inf(out16[:M].float().cpu(), ref.float().cpu())
-    old = torch.empty((M, Dout), device="cuda")
-    ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out=old, frag=frag)
-    d = rel_inf(out[:M].cpu(), old.cpu())
-    print(f"gen2 {fmt} sizes {sizes[:3]}.. F {F}: vs fp64 {e32:.2e} (16-bit out {e16:.2e}), vs gen1 {d:.2e}")
+    d = None
+    if Din % 64 == 0:
+        old = torch.empty((M, Dout), device="cuda")
+        L.lib().mdm_set_gemm_variant(34)  # the LDS-staged kernel of csrc/mlp.hip
+        try:
+            ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out=old, wstream=ws)
+        finally:
+            L.lib().mdm_set_gemm_variant(0)
+        d = rel_inf(out[:M].cpu(), old.cpu())
+    print(f"stream {fmt} sizes {sizes[:3]}.. F {F} Din {Din}: vs fp64 {e32:.2e} (16-bit out {e16:.2e}), vs LDS-staged {d}")
     tol = 3e-3 if dtype == torch.bfloat16 else 6e-4
-    assert e32 < tol and e16 < 4 * tol and d < 2 * tol
+    assert e32 < tol and e16 < 4 * tol and (d is None or d < 2 * tol)
     assert torch.all(out[M:] == 7.0) and torch.all(out16[M:] == 0)
-    assert not torch.equal(out[:M], old)  # the knob really selects the other kernel
+
+
+def test_streamed_weight_kernel_dense_with_residuals():
+    """No groups, no gather, both residual inputs, no biases: the dense Linear-GELU-Linear form."""
+    ops = pkg("ops")
+    for M, Din, F in [(300, 512, 2048), (1, 128, 256), (1000, 512, 512)]:
+        Dout = 512
+        x16 = _rand(M, Din, seed=1).to(torch.float16)
+        w1, b1 = _rand(F, Din, seed=2, scale=Din ** -0.5), _rand(F, seed=3, scale=0.1)
+        w2, b2 = _rand(Dout, F, seed=4, scale=F ** -0.5), _rand(Dout, seed=5, scale=0.1)
+        r1, r2 = _rand(M, Dout, seed=6), _rand(M, Dout, seed=7)
+        pw1, pw2 = ops.PackedWeight(w1, fmt="f16"), ops.PackedWeight(w2, fmt="f16")
+        ws = ops.mlp_stream_pack(w1, w2, torch.float16)
+        y = ops.fused_mlp(x16, pw1, b1, pw2, b2, r1=r1, r1_scale=0.5, r2=r2, wstream=ws)
+        h = torch.nn.functional.gelu(x16.double() @ w1.half().double().T + b1.double())
+        ref = (h.float().half().double() @ w2.half().double().T + b2.double() + 0.5 * r1.double() + r2.double()).float()
+        assert rel_inf(y.cpu(), ref.cpu()) < 6e-4
+        plain = ops.fused_mlp(x16, pw1, None, pw2, None, wstream=ws)
+        h0 = torch.nn.functional.gelu(x16.double() @ w1.half().double().T)
+        ref0 = (h0.float().half().double() @ w2.half().double().T).float()
+        assert rel_inf(plain.cpu(), ref0.cpu()) < 6e-4
