@@ -183,14 +183,15 @@ def expert_mlp_rate(m, B2, T):
     rows, G = 4 * M, 2 * E
     g = torch.Generator(device="cpu").manual_seed(0)
     x16 = torch.randn(2 * M, D, generator=g).to(dev).to(h16)
-    w1 = ops.PackedWeight((torch.randn(G, F_, D, generator=g) * D ** -0.5).to(dev), fmt=fmt)
-    w2 = ops.PackedWeight((torch.randn(G, D, F_, generator=g) * F_ ** -0.5).to(dev), fmt=fmt)
+    w1s, w2s = (torch.randn(G, F_, D, generator=g) * D ** -0.5).to(dev), (torch.randn(G, D, F_, generator=g) * F_ ** -0.5).to(dev)
+    w1, w2 = ops.PackedWeight(w1s, fmt=fmt), ops.PackedWeight(w2s, fmt=fmt)
     b1, b2 = torch.zeros(G, F_, device=dev), torch.zeros(G, D, device=dev)
     gather = torch.randint(0, 2 * M, (rows,), generator=g, dtype=torch.int32).to(dev)
     goff = (torch.arange(G + 1, dtype=torch.int64) * rows // G).to(torch.int32).to(dev)
     rs = torch.rand(rows, generator=g).to(dev)
     out = torch.empty(rows, D, device=dev)
-    dt = time_block(lambda: ops.fused_mlp(x16, w1, b1, w2, b2, gather=gather, goff=goff, rowscale=rs, rows=rows, out=out))
+    ws = ops.mlp_stream_pack(w1s, w2s, h16)  # the weight stream the model's packer builds (csrc/mlp_stream.hip)
+    dt = time_block(lambda: ops.fused_mlp(x16, w1, b1, w2, b2, gather=gather, goff=goff, rowscale=rs, rows=rows, out=out, wstream=ws))
     return dt, 4.0 * rows * D * F_
 
 
@@ -428,7 +429,7 @@ def main():
         }
         if dom is not None:
             line["roofline"]["dominant_kernel_alone"] = {
-                "name": "fused_mlp_kernel (expert W1-GELU-W2, csrc/mlp.hip)", "achieved": round(dom[1] / dom[0] / 1e12, 2),
+                "name": "fused_mlp_xres_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip)", "achieved": round(dom[1] / dom[0] / 1e12, 2),
                 "us": round(dom[0] * 1e6, 1), "frac": round(dom[1] / dom[0] / PEAK[a.precision], 4),
                 "flop_per_launch": dom[1], "timed_with": "HIP events on the launch stream, kernel alone, balanced routing"}
         if live is not None:
@@ -437,17 +438,17 @@ def main():
             if traffic is not None:
                 per = json.load(open(pmc))["per_kernel_MB_per_call"]
                 per = per.items() if isinstance(per, dict) else per
-                pk = next((v for k, v in per if str(k).startswith("fused_mlp_kernel")), None)
+                pk = next((v for k, v in per if str(k).startswith("fused_mlp")), None)
                 pmc_k = (pk["fetch_x2"] + pk["write"]) * 1e6 if pk else None
             rf = line["roofline"]
             rf.update({"achieved": round(live[1] / live[0] / 1e12, 2), "frac": round(live[1] / live[0] / PEAK[a.precision], 4),
                        "traffic": pmc_k,
                        "traffic_note": "fabric bytes per launch of this kernel (mean over its launches in a step), rocprofv3 "
                                        "--pmc FETCH_SIZE(x2) / WRITE_SIZE passes, profiles/r02_pmc_traffic.json" if pmc_k else None,
-                       "what": "dominant kernel fused_mlp_kernel (expert W1-GELU-W2, csrc/mlp.hip): mean algorithmic FLOP per "
+                       "what": "dominant kernel fused_mlp_xres_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip): mean algorithmic FLOP per "
                                "launch (4 * routed rows * D * F) / mean launch duration over the launches of real sampling "
                                "steps; the whole step is under whole_step",
-                       "kernel": "fused_mlp_kernel", "launch_us_mean": round(live[0] * 1e6, 1),
+                       "kernel": "fused_mlp_xres_kernel", "launch_us_mean": round(live[0] * 1e6, 1),
                        "flop_per_launch_mean": live[1], "launches_timed": len(live[2]),
                        "launches": [{"rows": rw, "us": round(u, 1)} for rw, u in live[2][:8]],
                        "timed_with": "HIP events recorded by the library on the launch stream around every launch of the "

@@ -146,6 +146,25 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
   const f32x2 e = x * p * r;
   return 0.5f * v * (1.0f + e);
 }
+// GELU as x * sigmoid(q(x)), q(x) = x (c0 + c1 x^2 + c2 x^4 + c3 x^6 + c4 x^8) fitted to the exact erf form on |x| <= 6.5
+// (beyond it the sigmoid is 1 - 9e-8 / 9e-8 and the argument is clamped); the coefficients carry the factor -log2(e) so that
+// the hardware exp2 takes them directly.  |error| <= 3.5e-6 absolute against the erf form (tests/test_host_logic.py), 70x
+// below the fp16 rounding of the hidden unit it produces, so it is used only where the result is rounded to 16 bits right
+// after (the fused expert MLP).  14 instructions per PAIR of values (4 packed FMAs, 2 exp2, 2 rcp) against 24 for gelu_erf2.
+// (The degree-7 fit, 1.2e-5, is a SYSTEMATIC error: summed over 1024 hidden units it showed as 1.4e-4 of the block output.)
+__device__ __forceinline__ f32x2 gelu_sig2(f32x2 v) {
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(v[0], -6.5f, 6.5f), __builtin_amdgcn_fmed3f(v[1], -6.5f, 6.5f)};
+  const f32x2 x2 = xc * xc;
+  f32x2 p = __builtin_elementwise_fma(x2, (f32x2){-3.229054982512025e-06f, -3.229054982512025e-06f},
+                                      (f32x2){8.82392268977128e-05f, 8.82392268977128e-05f});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){0.00036026936140842736f, 0.00036026936140842736f});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){-0.10522668063640594f, -0.10522668063640594f});
+  p = __builtin_elementwise_fma(p, x2, (f32x2){-2.3020453453063965f, -2.3020453453063965f});
+  const f32x2 t = p * xc;
+  const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+  const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return v * r;
+}
 // exp on the hardware exp2 unit (v_exp_f32): ~1e-6 relative error for |x| <= 15, 2 instructions instead of ~25.
 // Used only where the result is rounded to bf16 right after (throughput-mode attention cores).
 __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }

@@ -190,7 +190,9 @@ def mlp_stream_pack_reference(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.d
     Dout = w2.shape[1]
     NJ, Cn, KT = Dout // 128, F // 256, Din // 32
     a = w1.reshape(G, Cn, 8, 2, 16, KT, 4, 8).permute(0, 2, 1, 5, 3, 6, 4, 7)      # g, w, c, step, j, q, r, e
-    b = w2.reshape(G, 8, NJ, 16, Cn, 8, 4, 8).permute(0, 1, 4, 5, 2, 6, 3, 7)      # g, w, c, s, j, q, r, e
+    # hidden-image position p = 128 h + 16 w' + u holds unit 32 w' + 16 h + u of the chunk: reorder w2's k axis to p first
+    w2p = w2.reshape(G, Dout, Cn, 8, 2, 16).permute(0, 1, 2, 4, 3, 5).reshape(G, Dout, F)      # (.., w', h, u) -> (.., h, w', u)
+    b = w2p.reshape(G, 8, NJ, 16, Cn, 8, 4, 8).permute(0, 1, 4, 5, 2, 6, 3, 7)     # g, w, c, s, j, q, r, e
     s = torch.cat([a.reshape(G, 8, Cn, -1), b.reshape(G, 8, Cn, -1)], dim=3).to(dtype).reshape(-1)
     return torch.cat([s, torch.zeros(8 * 512, dtype=dtype, device=s.device)])
 

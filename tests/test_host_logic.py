@@ -187,6 +187,29 @@ def test_erf_rational_of_the_kernels_is_accurate():
     assert float(np.abs(approx.astype(np.float64) - erf(x.astype(np.float64))).max()) < 5e-7
 
 
+def test_sigmoid_form_gelu_of_the_fused_mlp_is_accurate():
+    """gelu_sig2 (csrc/mdm_common.h), the GELU of the streamed-weight expert MLP: x * sigmoid(q(x)) with the header's
+    coefficients evaluated in fp32 as the kernel does; max abs error against the exact erf form over [-12, 12] < 5e-6."""
+    import os, re
+    from scipy.special import erf
+    from conftest import ROOT
+    src = open(os.path.join(ROOT, "motiondiffusion-moe_amd", "csrc", "mdm_common.h")).read()
+    body = src[src.index("f32x2 gelu_sig2(f32x2 v)"):src.index("// exp on the hardware exp2 unit")]
+    nums = [float(v) for v in re.findall(r"(-?\d\.\d+(?:e[-+]\d+)?)f", body)]
+    clamp, cs = nums[:4], nums[4:14:2]
+    assert clamp == [-6.5, 6.5, -6.5, 6.5] and len(cs) == 5, nums
+    x = np.linspace(-12, 12, 480001).astype(np.float32)
+    xc = np.clip(x, -6.5, 6.5)
+    x2 = (xc * xc).astype(np.float32)
+    p = np.full_like(x2, np.float32(cs[0]))
+    for c in cs[1:]:
+        p = (p.astype(np.float64) * x2.astype(np.float64) + np.float64(np.float32(c))).astype(np.float32)
+    e = np.exp2((p * xc).astype(np.float32)).astype(np.float32)
+    got = (x / (np.float32(1) + e)).astype(np.float64)
+    want = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2.0)))
+    assert float(np.abs(got - want).max()) < 5e-6
+
+
 def test_load_balancing_loss_matches_reference_golden():
     """switch_moe.py:113-145 on given counters (tests/golden/moe_loss.npz, produced by the reference's own method)."""
     T = pkg("transformer")
