@@ -52,9 +52,8 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // Which tile this workgroup owns: groups are cut into ceil(rows / tile_h) tiles of equal height (a multiple of 16).  Lane e of
-// every wave looks at group e (at most 64 groups); false = no tile (the grid is an upper bound).
-__device__ __forceinline__ bool find_tile(const MdmMlpDesc& g, int tile_h, int lane, int& row0, int& row_end, int& grp) {
-  const int mt = xcd_remap(blockIdx.x, gridDim.x);  // contiguous tile ranges per XCD: an XCD's L2 serves ~2 groups
+// every wave looks at group e (at most 64 groups); mt = tile index; false = no such tile.
+__device__ __forceinline__ bool find_tile(const MdmMlpDesc& g, int tile_h, int lane, int mt, int& row0, int& row_end, int& grp) {
   const int ng = g.goff ? g.ngroups : 1;
   const int e = lane < ng ? lane : ng - 1;
   int b = 0, en = g.M;
@@ -85,7 +84,37 @@ template <typename HT, int RT, int NJ, int SMEM, int KO>
 __device__ __forceinline__ void store_tile(const MdmMlpDesc& g, f32x4 (&y)[RT][NJ], uint8_t* smem, int row0, int row_end, int tid,
                                            int wn, int frow, int fq) {
   constexpr int DOUT = NJ * 128;
-  // ---- epilogue: EPT row tiles at a time staged as fp32 [16 EPT][DOUT] in LDS, written as full rows ----------------------
+  if (!g.C && !g.R1 && !g.R2 && RT * 16 * DOUT * 2 <= SMEM) {
+    // 16-bit output only (the expert MLPs of the throughput modes): the whole tile staged once as 16-bit [rows][DOUT], one
+    // wave-instruction stores one full row (64 lanes x 16 B)
+    constexpr int ROWB = DOUT * 2, CH = ROWB / 16;  // 16-B chunks per row
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int ml = i * 16 + frow, m = row0 + ml;
+      const float rs = g.rowscale ? g.rowscale[m < row_end ? m : row_end - 1] : 1.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = wn * (16 * NJ) + 16 * j + 4 * fq;  // 4 consecutive columns = 8 bytes
+        const f32x4 v = y[i][j];
+        *(uint2*)(smem + ml * ROWB + ((((n >> 3) ^ (ml & (CH - 1))) << 4)) + ((n >> 2) & 1) * 8) =
+            make_uint2(HT::pack(v[0] * rs, v[1] * rs), HT::pack(v[2] * rs, v[3] * rs));
+      }
+    }
+    lds_barrier();
+    constexpr int TPR = CH, RPS = NT / TPR;  // threads per row, rows per sweep
+    const int cl = tid % TPR;
+#pragma unroll
+    for (int k = 0; k < (RT * 16 + RPS - 1) / RPS; ++k) {
+      const int ml = tid / TPR + RPS * k, m = row0 + ml;
+      if (ml >= RT * 16 || m >= row_end) continue;
+      const uint4 v = *(const uint4*)(smem + ml * ROWB + ((cl ^ (ml & (CH - 1))) << 4));
+      if (KO == 6 && v.x != 0x12345678u) continue;
+      *(uint4*)(g.C16 + (int64_t)m * g.ldc + cl * 8) = v;
+    }
+    return;
+  }
+  // ---- general form: EPT row tiles at a time staged as fp32 [16 EPT][DOUT] in LDS, written as full rows -------------------
   constexpr int EPT = SMEM / (16 * DOUT * 4) < RT ? SMEM / (16 * DOUT * 4) : RT;
   constexpr int NPASS = (RT + EPT - 1) / EPT;
   constexpr int CPR = DOUT / 4;  // float4 chunks per row
@@ -155,7 +184,8 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDes
   const int frow = lane & 15, fq = lane >> 4;
 
   int row0, row_end, grp;
-  if (!find_tile(g, tile_h, lane, row0, row_end, grp)) return;
+  // contiguous tile ranges per XCD: an XCD's L2 serves ~2 groups
+  if (!find_tile(g, tile_h, lane, xcd_remap(blockIdx.x, gridDim.x), row0, row_end, grp)) return;
 
   const int nchunk = g.F / FC, nko = g.Din / 128, nkt = g.Din / 64;
   const int fpc = (g.Din / 32) * 2 + 8 * NJ;  // fragments per (wave, chunk): phase 1 then phase 2
@@ -314,26 +344,55 @@ struct XGeo {
   static constexpr int SMEM = XIMG_B + HID_B;
 };
 
+// Diagnostic build KO == 9 (knob 49, tools/mlp_stamps.py): wave 0 of every workgroup sums s_memtime differences per phase and
+// adds them to the eight 64-bit counters that the R2 pointer of the descriptor points at (R2 is not read as a residual then).
+// Read the SHARES of this build, not its run time.
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define XSTAMP(k)                                  \
+  do {                                             \
+    if constexpr (KO == 9) {                       \
+      const unsigned long long n__ = stamp_now();  \
+      acc[k] += n__ - last;                        \
+      last = n__;                                  \
+    }                                              \
+  } while (0)
+
 template <typename HT, int RT, int NJ, int DIN, int KO>
 __global__ __launch_bounds__(NT, 2) void fused_mlp_xres_kernel(const MdmMlpDesc g, const int tile_h) {
   typedef typename HT::frag_t frag_t;
   typedef XGeo<RT, DIN> G;
   constexpr int DOUT = NJ * 128, NKO = DIN / 128, NLINE = DIN / 64;
+  constexpr int NA = KO == 8 ? 4 : RT, PD = NA - 1;  // A-fragment ring (knob 48: 4 registers, 3 ahead; default RT, RT - 1 ahead)
+  static_assert((4 * RT) % NA == 0, "the ring must close over the unrolled body");
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   uint8_t* const ximg = smem;
   uint8_t* const hid = smem + G::XIMG_B;
-  const int tid = threadIdx.x, lane = tid & 63;
+
+  unsigned long long acc[8] = {}, last = 0;
+  if constexpr (KO == 9) last = stamp_now();
+  // Persistent over tiles: workgroup b takes tiles remap(b), remap(b) + grid, ...; round k hands an XCD a contiguous range of
+  // tiles (~1 group: its weights stay in that XCD's L2).  The stores of a tile drain under the next tile's work.
+  for (int mt = xcd_remap(blockIdx.x, gridDim.x);; mt += gridDim.x) {
+  // the thread id is made opaque per tile: otherwise every lane-constant address of the body is hoisted out of this loop and
+  // lives in (spilled) registers across it -- 108 spilled registers; recomputing them per tile is a few dozen instructions
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fq = lane >> 4;
-
   int row0, row_end, grp;
-  if (!find_tile(g, tile_h, lane, row0, row_end, grp)) return;
+  if (!find_tile(g, tile_h, lane, mt, row0, row_end, grp)) break;
+  XSTAMP(0);
 
   const int nchunk = g.F / FC;
   constexpr int fpc = (DIN / 32) * 2 + 8 * NJ;
   const uint8_t* wp = (const uint8_t*)g.wstream + ((int64_t)grp * g.wstream_gs + (int64_t)wn * nchunk * fpc * 512) * 2 + lane * 16;
-  const float* b1 = g.b1 ? g.b1 + (int64_t)grp * g.b1_gs + wn * 32 + fq * 4 : nullptr;
-  const float* b2 = g.b2 ? g.b2 + (int64_t)grp * g.b2_gs + wn * (16 * NJ) + fq * 4 : nullptr;
 
   frag_t R[8];
 #pragma unroll
@@ -370,55 +429,71 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_xres_kernel(const MdmMlpDesc 
     }
   }
   f32x4 y[RT][NJ];
+  {
+    const float* b2 = g.b2 ? g.b2 + (int64_t)grp * g.b2_gs + wn * (16 * NJ) + fq * 4 : nullptr;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const f32x4 bb = b2 ? *(const f32x4*)(b2 + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) {
+      const f32x4 bb = b2 ? *(const f32x4*)(b2 + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < RT; ++i) y[i][j] = bb;
+      for (int i = 0; i < RT; ++i) y[i][j] = bb;
+    }
   }
   lds_barrier();
+  XSTAMP(1);
 
-  // fragment read bases
-  const uint8_t* const xa = ximg + frow * G::XROW_B;
-  const uint8_t* const ha = hid + frow * 256;
-  int xo[4];  // step 4 ko + u reads chunk 16 ko + ((4 u + fq) ^ frow)
-#pragma unroll
-  for (int u = 0; u < 4; ++u) xo[u] = ((4 * u + fq) ^ frow) << 4;
-
+#pragma unroll 1
   for (int chunk = 0; chunk < nchunk; ++chunk) {
+    // Lane-constant addresses are recomputed per chunk from an opaque copy of the lane id, so that nothing but the
+    // accumulators, the weight ring and the stream pointer lives across the phases (the register file is the limit here).
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int fr = ln & 15, fc = (ln >> 4) ^ fr;  // fc: the XOR-swizzled chunk of K step 0; step u reads chunk (4 u) ^ fc
     // ---- phase 1 (no barrier): h[rows x 32 units of this wave] = X . W1 chunk^T ---------------------------------------------
     f32x4 h[RT][2];
+    {
+      const float* b1 = g.b1 ? g.b1 + (int64_t)grp * g.b1_gs + wn * 32 + (ln >> 4) * 4 + chunk * FC : nullptr;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const f32x4 bb = b1 ? *(const f32x4*)(b1 + chunk * FC + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 bb = b1 ? *(const f32x4*)(b1 + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < RT; ++i) h[i][j] = bb;
-    }
-#pragma unroll 1
-    for (int ko = 0; ko < NKO; ++ko) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint8_t* sa = xa + ko * 256 + xo[u];
-        frag_t a[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) a[i] = *(const frag_t*)(sa + i * 16 * G::XROW_B);
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          if constexpr (KO == 4) {
-            asm volatile("" ::"v"(a[i]), "v"(R[2 * u]), "v"(R[2 * u + 1]));
-          } else {
-            h[i][0] = HT::mfma16(R[2 * u], a[i], h[i][0]);
-            h[i][1] = HT::mfma16(R[2 * u + 1], a[i], h[i][1]);
-          }
-        }
-        if constexpr (KO != 2) {
-          R[2 * u] = ldg<frag_t>(wp + (2 * u) * 1024);
-          R[2 * u + 1] = ldg<frag_t>(wp + (2 * u + 1) * 1024);
-        }
-        pin_vmem();
+        for (int i = 0; i < RT; ++i) h[i][j] = bb;
       }
-      wp += 8192;
     }
+    {
+      // The 7 A fragments of a K step go through a ring of NA registers that runs PD = NA - 1 fragments ahead of the MFMAs,
+      // every { 2 MFMAs, 1 fragment read } pinned by a scheduling barrier: left alone, hipcc issues one read, waits for it and
+      // issues its two MFMAs (one exposed LDS round trip per 32 MFMA cycles) as soon as registers get tight.
+      const int xb = fr * G::XROW_B + (fc << 4);  // byte offset of (row fr, K step 0) in the X image; bits 6..7 flip per step
+      constexpr int NF = 4 * RT;                   // fragments per unrolled body (4 K steps)
+      frag_t A[NA];
+#pragma unroll
+      for (int k = 0; k < PD; ++k) A[k % NA] = *(const frag_t*)(ximg + (xb ^ (64 * (k / RT))) + (k % RT) * 16 * G::XROW_B);
+#pragma unroll 1
+      for (int ko = 0; ko < NKO; ++ko) {
+        const int kn = ko + 1 == NKO ? 0 : ko + 1;  // the body's last prefetches belong to the next body (the last ones are not used)
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          const int u = k / RT, i = k % RT;
+          if constexpr (KO == 4) {
+            asm volatile("" ::"v"(A[k % NA]), "v"(R[2 * u]), "v"(R[2 * u + 1]));
+          } else {
+            h[i][0] = HT::mfma16(R[2 * u], A[k % NA], h[i][0]);
+            h[i][1] = HT::mfma16(R[2 * u + 1], A[k % NA], h[i][1]);
+          }
+          const int kp = k + PD, up = (kp % NF) / RT, ip = kp % RT;
+          A[kp % NA] = *(const frag_t*)(ximg + (xb ^ (64 * up)) + (kp < NF ? ko : kn) * 256 + ip * 16 * G::XROW_B);
+          if (i == RT - 1) {
+            if constexpr (KO != 2) {
+              R[2 * u] = ldg<frag_t>(wp + (2 * u) * 1024);
+              R[2 * u + 1] = ldg<frag_t>(wp + (2 * u + 1) * 1024);
+            }
+          }
+          pin_vmem();
+        }
+        wp += 8192;
+      }
+    }
+    XSTAMP(2);
     // ---- GELU (bias already in h) -> packed 16-bit, both halves -------------------------------------------------------------
     uint2 pk[2][RT];
 #pragma unroll
@@ -430,40 +505,71 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_xres_kernel(const MdmMlpDesc 
         else if constexpr (KO != 1) g01 = gelu_sig2(g01), g23 = gelu_sig2(g23);
         pk[j][i] = make_uint2(HT::pack(g01[0], g01[1]), HT::pack(g23[0], g23[1]));
       }
+    XSTAMP(3);
     // ---- phase 2 in two halves through the one half-chunk image ------------------------------------------------------------
     // image position of this lane's four units of half j: 16 wn + 4 fq (+ r): chunk 2 wn + (fq >> 1), byte 8 (fq & 1)
-    uint8_t* const hw = hid + frow * 256 + (((2 * wn + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8;
+    uint8_t* const hw = hid + fr * 256 + (((2 * wn + (ln >> 5)) ^ fr) << 4) + ((ln >> 4) & 1) * 8;
+    const int hb = fr * 256 + (fc << 4);  // (row fr, K step 0) of the half image; step s reads chunk (4 s) ^ fc
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       lds_barrier();  // the image is free: every wave is past its reads of the previous half
 #pragma unroll
       for (int i = 0; i < RT; ++i) *(uint2*)(hw + i * 4096) = pk[hf][i];
       lds_barrier();  // published
+      XSTAMP(4);
+      {
+        constexpr int NF = 4 * RT;  // fragments of this half: 4 K steps x RT row tiles
+        frag_t A[NA];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        frag_t a[RT];
+        for (int k = 0; k < PD; ++k) A[k % NA] = *(const frag_t*)(hid + (hb ^ (64 * (k / RT))) + (k % RT) * 4096);
 #pragma unroll
-        for (int i = 0; i < RT; ++i) a[i] = *(const frag_t*)(ha + i * 4096 + (((4 * s + fq) ^ frow) << 4));
+        for (int k = 0; k < NF; ++k) {
+          const int sq = k / RT, i = k % RT;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int slot = ((4 * hf + s) * NJ + j) & 7;
-#pragma unroll
-          for (int i = 0; i < RT; ++i) {
+          for (int j = 0; j < NJ; ++j) {
+            const int slot = ((4 * hf + sq) * NJ + j) & 7;
             if constexpr (KO == 5) {
-              asm volatile("" ::"v"(a[i]), "v"(R[slot]));
+              asm volatile("" ::"v"(A[k % NA]), "v"(R[slot]));
             } else {
-              y[i][j] = HT::mfma16(R[slot], a[i], y[i][j]);
+              y[i][j] = HT::mfma16(R[slot], A[k % NA], y[i][j]);
             }
           }
-          if constexpr (KO != 2) R[slot] = ldg<frag_t>(wp + slot * 1024);
-          if (slot == 7) wp += 8192;
+          if (k + PD < NF) A[(k + PD) % NA] = *(const frag_t*)(hid + (hb ^ (64 * ((k + PD) / RT))) + ((k + PD) % RT) * 4096);
+          if (i == RT - 1) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              const int slot = ((4 * hf + sq) * NJ + j) & 7;
+              if constexpr (KO != 2) R[slot] = ldg<frag_t>(wp + slot * 1024);
+              if (slot == 7) wp += 8192;
+            }
+          }
           pin_vmem();
         }
       }
+      XSTAMP(5);
     }
   }
 
-  store_tile<HT, RT, NJ, G::SMEM, KO>(g, y, smem, row0, row_end, tid, wn, frow, fq);
+  // the epilogue derives its addresses from an opaque thread id of its own (see above)
+  int te = threadIdx.x;
+  asm volatile("" : "+v"(te));
+  if constexpr (KO == 9) {
+    MdmMlpDesc g2 = g;
+    g2.R2 = nullptr;
+    store_tile<HT, RT, NJ, G::SMEM, KO>(g2, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
+    XSTAMP(6);
+    if (tid == 0) atomicAdd((unsigned long long*)g.R2 + 7, 1ull);
+  } else {
+    store_tile<HT, RT, NJ, G::SMEM, KO>(g, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
+  }
+  lds_barrier();  // the staging reads of this tile are done before the next tile's X rows land in the same LDS
+  }
+  if constexpr (KO == 9) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) atomicAdd((unsigned long long*)g.R2 + q, acc[q]);
+    }
+  }
 }
 
 // ---- weight stream packing: fp32 / 16-bit row-major expert weights -> the per-(group, wave) fragment stream ------------
@@ -569,10 +675,11 @@ static int launch_stream(const MdmMlpDesc& a, hipStream_t stream) {
         return MDM_ERR_LAUNCH;
       attr = true;
     }
+    const int grid = tiles < device_cus() ? tiles : device_cus();  // persistent: one workgroup per CU walks the tiles
     if (a.h16 == MDM_H16_F16) {
-      hipLaunchKernelGGL((fused_mlp_xres_kernel<HF, RT, NJ, 512, KO>), dim3(tiles), dim3(NT), smem, stream, a, th);
+      hipLaunchKernelGGL((fused_mlp_xres_kernel<HF, RT, NJ, 512, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
     } else {
-      hipLaunchKernelGGL((fused_mlp_xres_kernel<HB, RT, NJ, 512, KO>), dim3(tiles), dim3(NT), smem, stream, a, th);
+      hipLaunchKernelGGL((fused_mlp_xres_kernel<HB, RT, NJ, 512, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
     }
     MDM_RETURN_IF_LAUNCH_FAILED();
     return MDM_OK;
@@ -606,6 +713,7 @@ int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream) {
     case 46: return launch_stream<6>(a, stream);
     case 47: return launch_stream<7>(a, stream);
     case 48: return launch_stream<8>(a, stream);
+    case 49: return launch_stream<9>(a, stream);
     default: return launch_stream<0>(a, stream);
   }
 }

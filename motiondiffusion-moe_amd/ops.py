@@ -200,7 +200,8 @@ def mlp_stream_pack_reference(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.d
 def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w2: PackedWeight,
               b2: Optional[torch.Tensor], *, gather=None, goff=None, rowscale=None, r1=None, r1_scale: float = 1.0,
               r2=None, rows: Optional[int] = None, out: Optional[torch.Tensor] = None,
-              out16: Optional[torch.Tensor] = None, wstream: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out16: Optional[torch.Tensor] = None, wstream: Optional[torch.Tensor] = None,
+              only16: bool = False) -> torch.Tensor:
     """y = (GELU(x w1^T + b1) w2^T + b2) * rowscale + r1_scale * r1 + r2 with the hidden layer kept on chip (mlp.hip;
     mlp_stream.hip when ``wstream`` is given).
     ``goff`` (int32 [G+1], device) selects grouped mode: w1 / w2 / b1 / b2 then carry a leading group axis."""
@@ -211,7 +212,9 @@ def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w
     M = x2.shape[0] if rows is None else rows
     F, Dout = w1.N, w2.N
     assert w1.K == x2.shape[1] and w2.K == F
-    if out is None:
+    if only16:  # 16-bit output only (what the model's expert MLPs write in the throughput modes): returns out16
+        assert out16 is not None and out is None
+    elif out is None:
         out = torch.empty((M, Dout), dtype=torch.float32, device=x16.device)
     d = L.MlpDesc()
     d.h16 = L.H16_F16 if x16.dtype == torch.float16 else L.H16_BF16
@@ -232,9 +235,10 @@ def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w
         d.R1, d.ldr1 = r1.data_ptr(), r1.stride(0)
     if r2 is not None:
         d.R2, d.ldr2 = r2.data_ptr(), r2.stride(0)
-    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    if out is not None:
+        d.C, d.ldc = out.data_ptr(), out.stride(0)
     if out16 is not None:
-        assert out16.stride(0) == out.stride(0)
-        d.C16 = out16.data_ptr()
+        assert out is None or out16.stride(0) == out.stride(0)
+        d.C16, d.ldc = out16.data_ptr(), out16.stride(0)
     L.check(L.lib().mdm_fused_mlp(C.byref(d), C.c_void_p(L.stream_ptr())), "mdm_fused_mlp")
-    return out
+    return out if out is not None else out16

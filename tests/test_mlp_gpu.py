@@ -138,6 +138,10 @@ def test_streamed_weight_kernel(dtype, sizes, F, Din):
     tol = 3e-3 if dtype == torch.bfloat16 else 6e-4
     assert e32 < tol and e16 < 4 * tol and (d is None or d < 2 * tol)
     assert torch.all(out[M:] == 7.0) and torch.all(out16[M:] == 0)
+    # 16-bit output only (the model's call): its own epilogue, same values as the 16-bit copy of the general one
+    only = torch.zeros((M + 3, Dout), dtype=dtype, device="cuda")
+    ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out16=only, wstream=ws, only16=True)
+    assert torch.equal(only.view(torch.int16), out16.view(torch.int16))
 
 
 def test_streamed_weight_kernel_dense_with_residuals():
