@@ -289,6 +289,66 @@ def mode_table(a, m_main, inputs, host, diff, kw, dev, main_prec, main_ms, steps
     return out
 
 
+def spawn_ranks(n: int) -> int:
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` as a child process,
+    relay its output, return its exit code (non-zero when any rank failed).  The caller has not initialised a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def dry_run(a, world, rank) -> None:
+    """The bench protocol without the GPU (tests/test_bench_launcher.py): gloo process group, W warm-up + K timed stand-in
+    steps between barriers, MAX over ranks, one all-gather of every rank's shard, ONE JSON line from rank 0."""
+    if world > 1:
+        dist.init_process_group("gloo")
+    dmod = importlib.import_module("motiondiffusion-moe_amd.dist")
+    B = a.batch
+    lo, hi = dmod.shard_range(B * world, rank, world)
+    x = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1, 1).expand(-1, 4, 3).contiguous()
+
+    def one_step():
+        x.mul_(1.0)
+
+    for _ in range(a.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0])
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    final = dmod.all_gather_ragged(x, B * world)
+    assert final.shape[0] == B * world and torch.equal(final[:, 0, 0], torch.arange(B * world, dtype=torch.float32))
+    if rank == 0:
+        print(json.dumps({"metric": "denoising-steps/sec (B=32, T=196, 263-d, 8 experts)", "value": a.steps / dt * world * (B / 32.0),
+                          "unit": "denoising-steps/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run: stand-in step on the CPU, gloo ranks (launcher rehearsal)",
+                                     "global_batch": B * world, "parallelism": f"batch-shard x{world}, weights replicated"}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,11 +370,21 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams the step's rows are split over")
     ap.add_argument("--variant", type=int, default=0, help="kernel-selection knob for same-box A/B runs (mdm_set_gemm_variant)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / timing-protocol rehearsal on the CPU: gloo ranks, a stand-in step, no GPU and no model")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process only LAUNCHES (it never touches a GPU); the ranks are N fresh
+        # processes under torch.distributed.run, one per GPU, and rank 0's JSON line comes back through our stdout
+        raise SystemExit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(a.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
+    if a.dry_run:
+        return dry_run(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the denoising path runs on hand-written HIP kernels only")
     torch.cuda.set_device(local)

@@ -19,6 +19,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.jo
          "-Wno-unused-result"]
 
 
+# per-file flags: the fused MLP keeps its GELU on scalar fp32 instructions (packed fp32 is slow beside MFMAs)
+EXTRA = {"mlp_stream.hip": ["-fno-slp-vectorize"]}
+
+
 def _newer(src_list, target):
     if not os.path.exists(target):
         return True
@@ -38,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         s, o = job
-        cmd = ["hipcc"] + FLAGS + ["-c", s, "-o", o]
+        cmd = ["hipcc"] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-4000:]}")

@@ -3,21 +3,33 @@
 // row scale) and the dense Linear-GELU-Linear pairs (fast_attention.py:121-126,293-299).
 //
 // Decomposition (what differs from csrc/mlp.hip, whose weights cross LDS behind one barrier per K step):
-//   * one workgroup = 8 waves owns a tile of up to RT*16 rows and ALL Dout output columns.  The waves split the N axis
-//     only: wave w owns hidden units [32 w, 32 w + 32) of every 256-unit hidden chunk (phase 1) and output columns
-//     [16 NJ w, 16 NJ (w + 1)) (phase 2), for all rows of the tile.
-//   * the ACTIVATION operand (X k-tiles in phase 1, the GELU'd hidden chunk in phase 2) is what the waves share: it lives in
-//     LDS and every wave reads all of it (conflict-free XOR images, ds_read_b128 fragments);
+//   * one workgroup = 8 waves owns a tile of up to RT*16 rows and ALL Dout output columns; it is PERSISTENT: one workgroup per
+//     CU walks the tiles, the stores of a tile drain under the next tile's work.  The waves split the N axis only: wave w owns
+//     hidden units [32 w, 32 w + 32) of every 256-unit hidden chunk (phase 1) and output columns [16 NJ w, 16 NJ (w + 1))
+//     (phase 2), for all rows of the tile.
+//   * the ACTIVATION operand is what the waves share, so it lives in LDS and every wave reads all of it (XOR images,
+//     conflict-free ds_read_b128 fragments): the tile's X rows stay RESIDENT ([rows][Din] 16-bit, loaded once per tile), so
+//     phase 1 stages nothing and has no barrier; the GELU'd hidden chunk is published in two halves of 128 units through one
+//     28-KiB image (112 KiB of X + 56 KiB of hidden chunk would be 8 KiB over the 160 KiB of a CU): four barriers per chunk.
 //   * the WEIGHTS are private to a wave, so they never touch LDS: packed once as ONE linear stream of 1-KiB MFMA fragments
 //     per (group, wave) in exactly the order the wave consumes them (mdm_mlp_stream_pack), they go global -> registers with
 //     plain 16-byte loads through an 8-fragment register ring that runs 8 fragments (~0.9 k MFMA cycles) ahead.  No LDS-DMA,
-//     no barrier and no LDS read for 94 % of the bytes a tile moves; phase 2 has no barrier at all;
-//   * X k-tiles (64 k) are register-staged into a 3-stage LDS ring with ONE barrier per tile placed between the tile's two
-//     32-wide K steps, so no barrier is followed by an LDS round trip that an MFMA waits for;
+//     no barrier and no LDS read for 94 % of the bytes a tile moves.
+//   * the GELU (VALU) runs UNDER phase-2 MFMAs of the same wave: the order of a chunk is
+//         phase 1 (c)  ->  { phase 2, second half of chunk c - 1 }  with  GELU of half 0 of chunk c  interleaved
+//         -> publish half 0 ->  { phase 2, first half of chunk c }  with  GELU of half 1 of chunk c  interleaved  -> publish half 1
+//     (per { 4 MFMAs, 1 fragment read } one half of a value pair's GELU: ~2 VALU instructions per MFMA, what an MFMA's issue
+//     shadow holds); done back to back, the GELU of a chunk is 4.7 k cycles of every SIMD with its matrix pipe idle (15 % of a tile).
+//   * every { MFMAs of one A fragment, 1 fragment read, GELU piece } is pinned by a scheduling barrier, the A fragments go
+//     through a small register ring that runs ahead of the MFMAs: left alone hipcc sinks the weight refills of an unrolled
+//     body to its end (the ring's run-ahead collapses) and, once registers are tight, reads one fragment, waits, issues its
+//     MFMAs (one exposed LDS round trip per 32 MFMA cycles).
 //   * tiles are balanced: the launch picks the tile height so that the tiles of all groups fill the CUs in whole rounds
 //     (112-row tiles: 50176 routed rows = 448..464 tiles = 2 rounds at 7/8 of the rows a round could hold; the 128-row
 //     tiles of mlp.hip made 392 tiles = 2 rounds, the second 53 % full).
-// Register budget per lane (RT = 7, NJ = 4): y 112 + h 56 + weight ring 32 + A fragments + X staging 8.
+// Register budget per lane (RT = 7, NJ = 4): y 112 + h 56 + weight ring 32 + A ring 16 + GELU temporaries.
+#include <utility>
+
 #include "gemm.h"
 #include "kernels.h"
 
@@ -26,24 +38,14 @@ namespace {
 
 constexpr int NT = 512, FC = 256;
 
-template <int RT>
-struct SGeo {
-  static constexpr int ROWS = RT * 16;
-  static constexpr int HID_B = ROWS * FC * 2;  // one hidden chunk image, 16-bit [ROWS][256]: 512-B rows
-  static constexpr int XS_B = ROWS * 128;      // one X k-tile, 16-bit [ROWS][64]: 128-B rows
-  static constexpr int NXS = 3;
-  static constexpr int SMEM = 2 * HID_B + NXS * XS_B;
-};
-
 template <typename T>
 __device__ __forceinline__ T ldg(const uint8_t* p) {
   return *(const T*)p;
 }
 
-// Pins the weight refills where they are written: nothing may be scheduled across this point (a mask that lets LDS
-// reads, MFMAs and ALU work through is no pin at all: the scheduler then moves exactly those above it).  Without it hipcc sinks all refills of an unrolled body to its end and the run-ahead
-// (8 fragments) collapses to about one K step.
-__device__ __forceinline__ void pin_vmem() { __builtin_amdgcn_sched_barrier(0); }
+// Pins what is written before it: nothing may be scheduled across this point (a mask that lets LDS reads, MFMAs and ALU work
+// through is no pin at all: the scheduler then moves exactly those above it).
+__device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -88,6 +90,20 @@ __device__ __forceinline__ void store_tile(const MdmMlpDesc& g, f32x4 (&y)[RT][N
     // 16-bit output only (the expert MLPs of the throughput modes): the whole tile staged once as 16-bit [rows][DOUT], one
     // wave-instruction stores one full row (64 lanes x 16 B)
     constexpr int ROWB = DOUT * 2, CH = ROWB / 16;  // 16-B chunks per row
+    if constexpr (KO == 3) {  // knob 43: straight from the accumulators, 8 bytes per lane (16 rows x 32 B per instruction)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int m = row0 + i * 16 + frow;
+        const float rs = g.rowscale ? g.rowscale[m < row_end ? m : row_end - 1] : 1.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n = wn * (16 * NJ) + 16 * j + 4 * fq;
+          const f32x4 v = y[i][j];
+          if (m < row_end) *(uint2*)(g.C16 + (int64_t)m * g.ldc + n) = make_uint2(HT::pack(v[0] * rs, v[1] * rs), HT::pack(v[2] * rs, v[3] * rs));
+        }
+      }
+      return;
+    }
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
@@ -169,181 +185,6 @@ __device__ __forceinline__ void store_tile(const MdmMlpDesc& g, f32x4 (&y)[RT][N
   }
 }
 
-// KO: timing-only knock-outs for tools/mlp_bench.py (0 = the real kernel; results are wrong otherwise): 1 no GELU arithmetic,
-// 2 no weight refills, 3 no X staging, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores; 7 = the real kernel with the erf-form GELU of the LDS-staged kernel
-template <typename HT, int RT, int NJ, int KO>
-__global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h) {
-  typedef typename HT::frag_t frag_t;
-  typedef SGeo<RT> G;
-  constexpr int DOUT = NJ * 128;
-  extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
-  uint8_t* const hid = smem;
-  uint8_t* const xs = smem + 2 * G::HID_B;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int frow = lane & 15, fq = lane >> 4;
-
-  int row0, row_end, grp;
-  // contiguous tile ranges per XCD: an XCD's L2 serves ~2 groups
-  if (!find_tile(g, tile_h, lane, xcd_remap(blockIdx.x, gridDim.x), row0, row_end, grp)) return;
-
-  const int nchunk = g.F / FC, nko = g.Din / 128, nkt = g.Din / 64;
-  const int fpc = (g.Din / 32) * 2 + 8 * NJ;  // fragments per (wave, chunk): phase 1 then phase 2
-  // the wave's weight stream: per-lane pointer at fragment 0 (+ 16 B per lane)
-  const uint8_t* wp = (const uint8_t*)g.wstream + ((int64_t)grp * g.wstream_gs + (int64_t)wn * nchunk * fpc * 512) * 2 + lane * 16;
-  const float* b1 = g.b1 ? g.b1 + (int64_t)grp * g.b1_gs + wn * 32 + fq * 4 : nullptr;
-  const float* b2 = g.b2 ? g.b2 + (int64_t)grp * g.b2_gs + wn * (16 * NJ) + fq * 4 : nullptr;
-
-  // ---- X staging: thread -> row tid >> 2, 32 B of each 128-B k-tile row; waves >= RT have no rows ---------------------
-  const bool xact = wn < RT;
-  const int xr = tid >> 2;
-  const uint8_t* xp;
-  {
-    int srow = row0 + xr;
-    srow = srow < row_end ? srow : row_end - 1;
-    const int64_t src = g.gather ? (int64_t)g.gather[srow] : (int64_t)srow;
-    xp = (const uint8_t*)(g.X + src * g.ldx) + (tid & 3) * 32;
-  }
-  const int xw0 = xr * 128 + ((((tid & 3) * 2) ^ (xr & 7)) << 4);
-  const int xw1 = xr * 128 + ((((tid & 3) * 2 + 1) ^ (xr & 7)) << 4);
-  // fragment read bases: X tile row frow + 16 i, 16-B chunk (4 ks + fq) ^ (row & 7); hidden row, chunk (4 s + fq) ^ (row & 15)
-  const int xa0 = frow * 128 + ((fq ^ (frow & 7)) << 4), xa1 = frow * 128 + (((4 + fq) ^ (frow & 7)) << 4);
-  const int hrow = frow * 512;
-
-  // ---- prologue: weight ring, X tiles 0 (LDS stage 0) and 1 (registers) ------------------------------------------------
-  frag_t R[8];
-#pragma unroll
-  for (int f = 0; f < 8; ++f) R[f] = ldg<frag_t>(wp + f * 1024);
-  wp += 8192;  // wp + 1024 f is now the fragment that refills slot f
-  constexpr bool XD2 = KO == 8;  // X tiles requested two tiles ahead (two register sets) instead of one
-  uint4 xq0 = {}, xq1 = {}, xr0 = {}, xr1 = {};  // set q: odd tiles (XD2) / every tile; set r: even tiles (XD2 only)
-  if (xact) xq0 = ldg<uint4>(xp), xq1 = ldg<uint4>(xp + 16);
-  f32x4 y[RT][NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const f32x4 bb = b2 ? *(const f32x4*)(b2 + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < RT; ++i) y[i][j] = bb;
-  }
-  if (xact) {
-    *(uint4*)(xs + xw0) = xq0, *(uint4*)(xs + xw1) = xq1;
-    xq0 = ldg<uint4>(xp + 128), xq1 = ldg<uint4>(xp + 128 + 16);
-    if constexpr (XD2) xr0 = ldg<uint4>(xp + (nkt > 2 ? 256 : 0)), xr1 = ldg<uint4>(xp + (nkt > 2 ? 256 : 0) + 16);
-  }
-  lds_barrier();
-  int st = 0;  // LDS stage of the current X tile
-  int kn = XD2 ? (nkt > 3 ? 3 : 3 % nkt) : (nkt > 2 ? 2 : 0);  // k-tile index (mod nkt) of the next X tile to request
-
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    // ---- phase 1: h[rows x 32 units of this wave] = X . W1 chunk^T -----------------------------------------------------
-    f32x4 h[RT][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const f32x4 bb = b1 ? *(const f32x4*)(b1 + chunk * FC + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < RT; ++i) h[i][j] = bb;
-    }
-    for (int ko = 0; ko < nko; ++ko) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {  // K step 4 ko + u: X tile 2 ko + (u >> 1), half u & 1; ring slots 2u, 2u + 1
-        const uint8_t* sa = xs + st * G::XS_B + ((u & 1) ? xa1 : xa0);
-        frag_t a[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) a[i] = *(const frag_t*)(sa + i * 2048);
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          if constexpr (KO == 4) {
-            asm volatile("" ::"v"(a[i]), "v"(R[2 * u]), "v"(R[2 * u + 1]));
-          } else {
-            h[i][0] = HT::mfma16(R[2 * u], a[i], h[i][0]);
-            h[i][1] = HT::mfma16(R[2 * u + 1], a[i], h[i][1]);
-          }
-        }
-        if constexpr (KO != 2) {
-          R[2 * u] = ldg<frag_t>(wp + (2 * u) * 1024);
-          R[2 * u + 1] = ldg<frag_t>(wp + (2 * u + 1) * 1024);
-        }
-        if ((u & 1) == 0) {
-          // between the tile's two K steps: publish the next X tile (its stage was last read two tiles ago, and every wave
-          // has passed the previous barrier since), request the one after it
-          const int sn = st == 2 ? 0 : st + 1;
-          if (KO != 3 && xact) {
-            if (XD2 && u == 2) {  // odd tile: the next one (even) is in set r
-              *(uint4*)(xs + sn * G::XS_B + xw0) = xr0, *(uint4*)(xs + sn * G::XS_B + xw1) = xr1;
-              xr0 = ldg<uint4>(xp + kn * 128), xr1 = ldg<uint4>(xp + kn * 128 + 16);
-            } else {
-              *(uint4*)(xs + sn * G::XS_B + xw0) = xq0, *(uint4*)(xs + sn * G::XS_B + xw1) = xq1;
-              xq0 = ldg<uint4>(xp + kn * 128), xq1 = ldg<uint4>(xp + kn * 128 + 16);
-            }
-          }
-          kn = kn + 1 == nkt ? 0 : kn + 1;
-          lds_barrier();
-        } else {
-          st = st == 2 ? 0 : st + 1;
-        }
-      }
-      wp += 8192;
-    }
-    // ---- exact GELU (bias already in h) -> 16-bit hidden chunk image.  Every wave has passed a phase-1 barrier since it
-    // finished phase 2 of the previous chunk, so the image it read there is free.
-    {
-      uint8_t* hw = hid + (chunk & 1) * G::HID_B + hrow + (fq & 1) * 8;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c16 = 16 * j + 2 * wn + (fq >> 1);  // image position of unit 32 w + 16 j + u is 128 j + 16 w + u (stream k order)
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          f32x2 g01 = {h[i][j][0], h[i][j][1]}, g23 = {h[i][j][2], h[i][j][3]};
-          if constexpr (KO == 7) g01 = gelu_erf2(g01), g23 = gelu_erf2(g23);
-          else if constexpr (KO != 1) g01 = gelu_sig2(g01), g23 = gelu_sig2(g23);
-          *(uint2*)(hw + i * 8192 + ((c16 ^ frow) << 4)) = make_uint2(HT::pack(g01[0], g01[1]), HT::pack(g23[0], g23[1]));
-        }
-      }
-    }
-    lds_barrier();
-    // ---- phase 2: y += hidden chunk . W2[:, chunk]^T, 8 K steps of 32, NJ fragments each; no barrier ---------------------
-    const uint8_t* hb = hid + (chunk & 1) * G::HID_B + hrow;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      frag_t a[RT];
-#pragma unroll
-      for (int i = 0; i < RT; ++i) a[i] = *(const frag_t*)(hb + i * 8192 + (((4 * s + fq) ^ frow) << 4));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int slot = (s * NJ + j) & 7;
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          if constexpr (KO == 5) {
-            asm volatile("" ::"v"(a[i]), "v"(R[slot]));
-          } else {
-            y[i][j] = HT::mfma16(R[slot], a[i], y[i][j]);
-          }
-        }
-        if constexpr (KO != 2) R[slot] = ldg<frag_t>(wp + slot * 1024);
-        if (slot == 7) wp += 8192;
-      }
-    }
-  }
-
-  store_tile<HT, RT, NJ, G::SMEM, KO>(g, y, smem, row0, row_end, tid, wn, frow, fq);
-}
-
-// =====================================================================================================================
-// Second form (the default): the tile's X rows stay RESIDENT in LDS ([rows][Din] 16-bit, loaded once per tile instead of
-// once per hidden chunk), so phase 1 stages nothing and has NO barrier: 16 K steps of { 7 fragment reads, 14 MFMAs, 2 weight
-// refills } per wave, the waves free to drift apart.  What pays for it: the hidden chunk is published in two halves of 128
-// units through one 28-KiB image (112 KiB of X + 56 KiB of hidden chunk would be 8 KiB over the 160 KiB of a CU), i.e.
-// four barriers per chunk: [image free] write half 0 [published] phase 2a [read] write half 1 [published] phase 2b.  The
-// half that waits is held as packed 16-bit values (14 registers).
-template <int RT, int DIN>
-struct XGeo {
-  static constexpr int ROWS = RT * 16;
-  static constexpr int XROW_B = DIN * 2;     // X image: 16-B chunk c of row m at slot c ^ (m & 15)
-  static constexpr int XIMG_B = ROWS * XROW_B;
-  static constexpr int HID_B = ROWS * 256;   // half hidden chunk, 16-bit [ROWS][128]: chunk c of row m at slot c ^ (m & 15)
-  static constexpr int SMEM = XIMG_B + HID_B;
-};
-
 // Diagnostic build KO == 9 (knob 49, tools/mlp_stamps.py): wave 0 of every workgroup sums s_memtime differences per phase and
 // adds them to the eight 64-bit counters that the R2 pointer of the descriptor points at (R2 is not read as a residual then).
 // Read the SHARES of this build, not its run time.
@@ -363,13 +204,46 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     }                                              \
   } while (0)
 
+template <int RT, int DIN>
+struct XGeo {
+  static constexpr int ROWS = RT * 16;
+  static constexpr int XROW_B = DIN * 2;     // X image: 16-B chunk c of row m at slot c ^ (m & 15)
+  static constexpr int XIMG_B = ROWS * XROW_B;
+  static constexpr int HID_B = ROWS * 256;   // half hidden chunk, 16-bit [ROWS][128]: chunk c of row m at slot c ^ (m & 15)
+  static constexpr int SMEM = XIMG_B + HID_B;
+};
+
+// The GELU of one value pair in two pieces (so that a piece fits beside the four MFMAs of one A fragment): gelu_sig2 of
+// mdm_common.h cut after the exp2, written on SCALAR fp32 operations: beside MFMAs a packed-fp32 instruction (v_pk_fma_f32)
+// costs several times two plain ones (MI355X guide, cycle constants), and this file is compiled with -fno-slp-vectorize so
+// that hipcc does not re-pack them.
+__device__ __forceinline__ float gelu_a1(float v) {
+  const float xc = __builtin_amdgcn_fmed3f(v, -6.5f, 6.5f);
+  const float x2 = xc * xc;
+  float p = fmaf(x2, -3.229054982512025e-06f, 8.82392268977128e-05f);
+  p = fmaf(p, x2, 0.00036026936140842736f);
+  p = fmaf(p, x2, -0.10522668063640594f);
+  p = fmaf(p, x2, -2.3020453453063965f);
+  return __builtin_amdgcn_exp2f(p * xc);
+}
+__device__ __forceinline__ f32x2 gelu_part_a(f32x2 v) { return (f32x2){gelu_a1(v[0]), gelu_a1(v[1])}; }
+__device__ __forceinline__ f32x2 gelu_part_b(f32x2 v, f32x2 e) {
+  return (f32x2){v[0] * __builtin_amdgcn_rcpf(e[0] + 1.0f), v[1] * __builtin_amdgcn_rcpf(e[1] + 1.0f)};
+}
+
+// KO: timing-only knock-outs for tools/mlp_ko.py (0 = the real kernel; results are wrong otherwise): 1 no GELU arithmetic,
+// 2 no weight refills, 3 = real kernel with the 16-bit outputs stored straight from the accumulators, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores; 7 = the real kernel with the erf-form GELU
+// of the LDS-staged kernel (not interleaved); 8 = GELU not interleaved (back to back before the publish); 9 = stamped build
 template <typename HT, int RT, int NJ, int DIN, int KO>
-__global__ __launch_bounds__(NT, 2) void fused_mlp_xres_kernel(const MdmMlpDesc g, const int tile_h) {
+__global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h) {
   typedef typename HT::frag_t frag_t;
   typedef XGeo<RT, DIN> G;
-  constexpr int DOUT = NJ * 128, NKO = DIN / 128, NLINE = DIN / 64;
-  constexpr int NA = KO == 8 ? 4 : RT, PD = NA - 1;  // A-fragment ring (knob 48: 4 registers, 3 ahead; default RT, RT - 1 ahead)
-  static_assert((4 * RT) % NA == 0, "the ring must close over the unrolled body");
+  constexpr int NKO = DIN / 128, NLINE = DIN / 64;
+  constexpr int NA = 4, PD = NA - 1;  // A-fragment ring: NA registers, PD fragments ahead of the MFMAs
+  constexpr int NF = 4 * RT;          // A fragments per unrolled body (4 K steps x RT row tiles)
+  constexpr bool ILV = KO != 7 && KO != 8;  // GELU pieces interleaved with phase-2 MFMAs
+  static_assert(NF % NA == 0, "the ring must close over the unrolled body");
+  static_assert(NF >= 4 * RT, "one GELU pair piece per fragment: 2 RT pairs x 2 pieces");
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   uint8_t* const ximg = smem;
   uint8_t* const hid = smem + G::XIMG_B;
@@ -377,94 +251,146 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_xres_kernel(const MdmMlpDesc 
   unsigned long long acc[8] = {}, last = 0;
   if constexpr (KO == 9) last = stamp_now();
   // Persistent over tiles: workgroup b takes tiles remap(b), remap(b) + grid, ...; round k hands an XCD a contiguous range of
-  // tiles (~1 group: its weights stay in that XCD's L2).  The stores of a tile drain under the next tile's work.
+  // tiles (~1 group: its weights stay in that XCD's L2).
   for (int mt = xcd_remap(blockIdx.x, gridDim.x);; mt += gridDim.x) {
-  // the thread id is made opaque per tile: otherwise every lane-constant address of the body is hoisted out of this loop and
-  // lives in (spilled) registers across it -- 108 spilled registers; recomputing them per tile is a few dozen instructions
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
-  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int frow = lane & 15, fq = lane >> 4;
-  int row0, row_end, grp;
-  if (!find_tile(g, tile_h, lane, mt, row0, row_end, grp)) break;
-  XSTAMP(0);
+    // the thread id is made opaque per tile (and again per chunk / for the epilogue): otherwise every lane-constant address of
+    // the body is hoisted out of this loop and lives in (spilled) registers across it; recomputing is a few instructions
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int row0, row_end, grp;
+    if (!find_tile(g, tile_h, lane, mt, row0, row_end, grp)) break;
+    XSTAMP(0);
 
-  const int nchunk = g.F / FC;
-  constexpr int fpc = (DIN / 32) * 2 + 8 * NJ;
-  const uint8_t* wp = (const uint8_t*)g.wstream + ((int64_t)grp * g.wstream_gs + (int64_t)wn * nchunk * fpc * 512) * 2 + lane * 16;
+    const int nchunk = g.F / FC;
+    constexpr int fpc = (DIN / 32) * 2 + 8 * NJ;
+    const uint8_t* wp = (const uint8_t*)g.wstream + ((int64_t)grp * g.wstream_gs + (int64_t)wn * nchunk * fpc * 512) * 2 + lane * 16;
 
-  frag_t R[8];
+    frag_t R[8];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) R[f] = ldg<frag_t>(wp + f * 1024);
-  wp += 8192;
+    for (int f = 0; f < 8; ++f) R[f] = ldg<frag_t>(wp + f * 1024);
+    wp += 8192;  // wp + 1024 f is now the fragment that refills slot f
 
-  // ---- X tile -> LDS: wave w < RT brings rows 16 w .. 16 w + 15; one instruction = 8 rows x one 128-B line ----------------
-  if (wn < RT) {
-    const uint8_t* xp[2];
+    // ---- X tile -> LDS: wave w < RT brings rows 16 w .. 16 w + 15; one instruction = 8 rows x one 128-B line ---------------
+    if (wn < RT) {
+      const uint8_t* xp[2];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const int r = 16 * wn + 8 * hf + (lane >> 3);
-      int srow = row0 + r;
-      srow = srow < row_end ? srow : row_end - 1;
-      const int64_t src = g.gather ? (int64_t)g.gather[srow] : (int64_t)srow;
-      xp[hf] = (const uint8_t*)(g.X + src * g.ldx) + (lane & 7) * 16;
-    }
+      for (int hf = 0; hf < 2; ++hf) {
+        const int r = 16 * wn + 8 * hf + (lane >> 3);
+        int srow = row0 + r;
+        srow = srow < row_end ? srow : row_end - 1;
+        const int64_t src = g.gather ? (int64_t)g.gather[srow] : (int64_t)srow;
+        xp[hf] = (const uint8_t*)(g.X + src * g.ldx) + (lane & 7) * 16;
+      }
+      constexpr int LB = NLINE < 4 ? NLINE : 4;
 #pragma unroll
-    for (int c0 = 0; c0 < NLINE; c0 += 4) {
-      uint4 v[2][4];
+      for (int c0 = 0; c0 < NLINE; c0 += LB) {
+        uint4 v[2][LB];
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < LB; ++c)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) v[hf][c] = ldg<uint4>(xp[hf] + (c0 + c) * 128);
+          for (int hf = 0; hf < 2; ++hf) v[hf][c] = ldg<uint4>(xp[hf] + (c0 + c) * 128);
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < LB; ++c)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          // 16-B chunk 8 (c0 + c) + (lane & 7) of row r goes to slot chunk ^ (r & 15)
-          const int r = 16 * wn + 8 * hf + (lane >> 3);
-          const int ch = (8 * (c0 + c) + (lane & 7)) ^ (r & 15);
-          *(uint4*)(ximg + r * G::XROW_B + (ch << 4)) = v[hf][c];
-        }
-    }
-  }
-  f32x4 y[RT][NJ];
-  {
-    const float* b2 = g.b2 ? g.b2 + (int64_t)grp * g.b2_gs + wn * (16 * NJ) + fq * 4 : nullptr;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const f32x4 bb = b2 ? *(const f32x4*)(b2 + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < RT; ++i) y[i][j] = bb;
-    }
-  }
-  lds_barrier();
-  XSTAMP(1);
-
-#pragma unroll 1
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    // Lane-constant addresses are recomputed per chunk from an opaque copy of the lane id, so that nothing but the
-    // accumulators, the weight ring and the stream pointer lives across the phases (the register file is the limit here).
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int fr = ln & 15, fc = (ln >> 4) ^ fr;  // fc: the XOR-swizzled chunk of K step 0; step u reads chunk (4 u) ^ fc
-    // ---- phase 1 (no barrier): h[rows x 32 units of this wave] = X . W1 chunk^T ---------------------------------------------
-    f32x4 h[RT][2];
-    {
-      const float* b1 = g.b1 ? g.b1 + (int64_t)grp * g.b1_gs + wn * 32 + (ln >> 4) * 4 + chunk * FC : nullptr;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const f32x4 bb = b1 ? *(const f32x4*)(b1 + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < RT; ++i) h[i][j] = bb;
+          for (int hf = 0; hf < 2; ++hf) {
+            // 16-B chunk 8 (c0 + c) + (lane & 7) of row r goes to slot chunk ^ (r & 15)
+            const int r = 16 * wn + 8 * hf + (lane >> 3);
+            const int ch = (8 * (c0 + c) + (lane & 7)) ^ (r & 15);
+            *(uint4*)(ximg + r * G::XROW_B + (ch << 4)) = v[hf][c];
+          }
       }
     }
+    f32x4 y[RT][NJ];
     {
-      // The 7 A fragments of a K step go through a ring of NA registers that runs PD = NA - 1 fragments ahead of the MFMAs,
-      // every { 2 MFMAs, 1 fragment read } pinned by a scheduling barrier: left alone, hipcc issues one read, waits for it and
-      // issues its two MFMAs (one exposed LDS round trip per 32 MFMA cycles) as soon as registers get tight.
+      const float* b2 = g.b2 ? g.b2 + (int64_t)grp * g.b2_gs + wn * (16 * NJ) + (lane >> 4) * 4 : nullptr;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const f32x4 bb = b2 ? *(const f32x4*)(b2 + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < RT; ++i) y[i][j] = bb;
+      }
+    }
+    lds_barrier();
+    XSTAMP(1);
+
+    f32x4 h[RT][2];
+    uint2 pk[RT];  // the GELU'd half that is about to be published, packed
+    // One half of phase 2 (K = the 128 hidden units of the image) with the GELU of the h[.][GJ] accumulators into pk[]
+    // interleaved (GJ < 0: none).  hb: byte offset of (row fr, K step 0) in the half image.
+    auto phase2 = [&](auto hf_c, auto gj_c, int hb) __attribute__((always_inline)) {
+      constexpr int HF = decltype(hf_c)::value, GJ = decltype(gj_c)::value;
+      frag_t A[NA];
+      f32x2 ge = {0.f, 0.f};
+      uint32_t plo = 0;
+#pragma unroll
+      for (int k = 0; k < PD; ++k) A[k % NA] = *(const frag_t*)(hid + (hb ^ (64 * (k / RT))) + (k % RT) * 4096);
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        const int sq = k / RT, i = k % RT;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int slot = ((4 * HF + sq) * NJ + j) & 7;
+          if constexpr (KO == 5) {
+            asm volatile("" ::"v"(A[k % NA]), "v"(R[slot]));
+          } else {
+            y[i][j] = HT::mfma16(R[slot], A[k % NA], y[i][j]);
+          }
+        }
+        if (k + PD < NF) A[(k + PD) % NA] = *(const frag_t*)(hid + (hb ^ (64 * ((k + PD) / RT))) + ((k + PD) % RT) * 4096);
+        if constexpr (GJ >= 0 && ILV) {
+          // fragment k carries piece k & 1 of value pair k >> 1: pair p = elements 2 (p & 1), 2 (p & 1) + 1 of h[p >> 1][GJ]
+          const int p = k >> 1, ig = p >> 1, e0 = 2 * (p & 1);
+          const f32x2 v = {h[ig][GJ][e0], h[ig][GJ][e0 + 1]};
+          if ((k & 1) == 0) {
+            ge = KO == 1 ? v : gelu_part_a(v);
+          } else {
+            const f32x2 gv = KO == 1 ? v : gelu_part_b(v, ge);
+            const uint32_t w = HT::pack(gv[0], gv[1]);
+            if ((p & 1) == 0) plo = w;
+            else pk[ig] = make_uint2(plo, w);
+          }
+        }
+        if (i == RT - 1) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int slot = ((4 * HF + sq) * NJ + j) & 7;
+            if constexpr (KO != 2) R[slot] = ldg<frag_t>(wp + slot * 1024);
+            if (slot == 7) wp += 8192;
+          }
+        }
+        pin();
+      }
+    };
+    // GELU of h[.][GJ] -> pk[] on its own (first chunk: there is no phase 2 to hide it under; knobs 7 / 8: always)
+    auto gelu_alone = [&](auto gj_c) __attribute__((always_inline)) {
+      constexpr int GJ = decltype(gj_c)::value;
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        f32x2 g01 = {h[i][GJ][0], h[i][GJ][1]}, g23 = {h[i][GJ][2], h[i][GJ][3]};
+        if constexpr (KO == 7) g01 = gelu_erf2(g01), g23 = gelu_erf2(g23);
+        else if constexpr (KO != 1) g01 = gelu_part_b(g01, gelu_part_a(g01)), g23 = gelu_part_b(g23, gelu_part_a(g23));
+        pk[i] = make_uint2(HT::pack(g01[0], g01[1]), HT::pack(g23[0], g23[1]));
+      }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, -1> IN;
+
+    // phase 1 of one chunk (no barrier): h[rows x 32 units of this wave] = X . W1 chunk^T + b1
+    auto phase1 = [&](int chunk, int ln) __attribute__((always_inline)) {
+      const int fr = ln & 15, fc = (ln >> 4) ^ fr;  // fc: the XOR-swizzled chunk of K step 0; step u reads chunk (4 u) ^ fc
+      {
+        const float* b1 = g.b1 ? g.b1 + (int64_t)grp * g.b1_gs + wn * 32 + (ln >> 4) * 4 + chunk * FC : nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 bb = b1 ? *(const f32x4*)(b1 + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < RT; ++i) h[i][j] = bb;
+        }
+      }
       const int xb = fr * G::XROW_B + (fc << 4);  // byte offset of (row fr, K step 0) in the X image; bits 6..7 flip per step
-      constexpr int NF = 4 * RT;                   // fragments per unrolled body (4 K steps)
       frag_t A[NA];
 #pragma unroll
       for (int k = 0; k < PD; ++k) A[k % NA] = *(const frag_t*)(ximg + (xb ^ (64 * (k / RT))) + (k % RT) * 16 * G::XROW_B);
@@ -488,81 +414,91 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_xres_kernel(const MdmMlpDesc 
               R[2 * u + 1] = ldg<frag_t>(wp + (2 * u + 1) * 1024);
             }
           }
-          pin_vmem();
+          pin();
         }
         wp += 8192;
       }
-    }
-    XSTAMP(2);
-    // ---- GELU (bias already in h) -> packed 16-bit, both halves -------------------------------------------------------------
-    uint2 pk[2][RT];
+    };
+    // publish pk[] as the half image: [image free] write [published]
+    auto publish = [&](int ln) __attribute__((always_inline)) {
+      const int fr = ln & 15;
+      // image position of this lane's four units of a half: 16 wn + 4 fq (+ r): chunk 2 wn + (fq >> 1), byte 8 (fq & 1)
+      uint8_t* const hw = hid + fr * 256 + (((2 * wn + (ln >> 5)) ^ fr) << 4) + ((ln >> 4) & 1) * 8;
+      lds_barrier();  // the image is free: every wave is past its reads of the half published before
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        f32x2 g01 = {h[i][j][0], h[i][j][1]}, g23 = {h[i][j][2], h[i][j][3]};
-        if constexpr (KO == 7) g01 = gelu_erf2(g01), g23 = gelu_erf2(g23);
-        else if constexpr (KO != 1) g01 = gelu_sig2(g01), g23 = gelu_sig2(g23);
-        pk[j][i] = make_uint2(HT::pack(g01[0], g01[1]), HT::pack(g23[0], g23[1]));
-      }
-    XSTAMP(3);
-    // ---- phase 2 in two halves through the one half-chunk image ------------------------------------------------------------
-    // image position of this lane's four units of half j: 16 wn + 4 fq (+ r): chunk 2 wn + (fq >> 1), byte 8 (fq & 1)
-    uint8_t* const hw = hid + fr * 256 + (((2 * wn + (ln >> 5)) ^ fr) << 4) + ((ln >> 4) & 1) * 8;
-    const int hb = fr * 256 + (fc << 4);  // (row fr, K step 0) of the half image; step s reads chunk (4 s) ^ fc
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      lds_barrier();  // the image is free: every wave is past its reads of the previous half
-#pragma unroll
-      for (int i = 0; i < RT; ++i) *(uint2*)(hw + i * 4096) = pk[hf][i];
+      for (int i = 0; i < RT; ++i) *(uint2*)(hw + i * 4096) = pk[i];
       lds_barrier();  // published
+    };
+    // Lane-constant addresses are recomputed per phase from an opaque copy of the lane id, so that nothing but the accumulators,
+    // the weight ring and the stream pointer lives across the phases (the register file is the limit here).
+    auto olane = [&]() __attribute__((always_inline)) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      return ln;
+    };
+    auto hbase = [](int ln) { return (ln & 15) * 256 + ((((ln >> 4) ^ (ln & 15))) << 4); };  // (row fr, K step 0) of the half image
+
+    // chunk 0: nothing to hide its first GELU under
+    {
+      const int ln = olane();
+      phase1(0, ln);
+      XSTAMP(2);
+      gelu_alone(I0());
+      XSTAMP(3);
+      publish(ln);
       XSTAMP(4);
-      {
-        constexpr int NF = 4 * RT;  // fragments of this half: 4 K steps x RT row tiles
-        frag_t A[NA];
-#pragma unroll
-        for (int k = 0; k < PD; ++k) A[k % NA] = *(const frag_t*)(hid + (hb ^ (64 * (k / RT))) + (k % RT) * 4096);
-#pragma unroll
-        for (int k = 0; k < NF; ++k) {
-          const int sq = k / RT, i = k % RT;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int slot = ((4 * hf + sq) * NJ + j) & 7;
-            if constexpr (KO == 5) {
-              asm volatile("" ::"v"(A[k % NA]), "v"(R[slot]));
-            } else {
-              y[i][j] = HT::mfma16(R[slot], A[k % NA], y[i][j]);
-            }
-          }
-          if (k + PD < NF) A[(k + PD) % NA] = *(const frag_t*)(hid + (hb ^ (64 * ((k + PD) / RT))) + ((k + PD) % RT) * 4096);
-          if (i == RT - 1) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-              const int slot = ((4 * hf + sq) * NJ + j) & 7;
-              if constexpr (KO != 2) R[slot] = ldg<frag_t>(wp + slot * 1024);
-              if (slot == 7) wp += 8192;
-            }
-          }
-          pin_vmem();
-        }
+      if constexpr (ILV) {
+        phase2(I0(), I1(), hbase(ln));
+      } else {
+        phase2(I0(), IN(), hbase(ln));
+        gelu_alone(I1());
       }
       XSTAMP(5);
+      publish(ln);
+      XSTAMP(4);
     }
-  }
+#pragma unroll 1
+    for (int chunk = 1; chunk < nchunk; ++chunk) {
+      const int ln = olane();
+      phase1(chunk, ln);
+      XSTAMP(2);
+      // the second half of the PREVIOUS chunk's phase 2 (published before this chunk's phase 1) with the GELU of this chunk's
+      // half 0 under it
+      if constexpr (ILV) {
+        phase2(I1(), I0(), hbase(ln));
+      } else {
+        phase2(I1(), IN(), hbase(ln));
+        gelu_alone(I0());
+      }
+      XSTAMP(5);
+      publish(ln);
+      XSTAMP(4);
+      if constexpr (ILV) {
+        phase2(I0(), I1(), hbase(ln));
+      } else {
+        phase2(I0(), IN(), hbase(ln));
+        gelu_alone(I1());
+      }
+      XSTAMP(5);
+      publish(ln);
+      XSTAMP(4);
+    }
+    phase2(I1(), IN(), hbase(olane()));  // the last chunk's second half
+    XSTAMP(5);
 
-  // the epilogue derives its addresses from an opaque thread id of its own (see above)
-  int te = threadIdx.x;
-  asm volatile("" : "+v"(te));
-  if constexpr (KO == 9) {
-    MdmMlpDesc g2 = g;
-    g2.R2 = nullptr;
-    store_tile<HT, RT, NJ, G::SMEM, KO>(g2, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
-    XSTAMP(6);
-    if (tid == 0) atomicAdd((unsigned long long*)g.R2 + 7, 1ull);
-  } else {
-    store_tile<HT, RT, NJ, G::SMEM, KO>(g, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
-  }
-  lds_barrier();  // the staging reads of this tile are done before the next tile's X rows land in the same LDS
+    // the epilogue derives its addresses from an opaque thread id of its own (see above)
+    int te = threadIdx.x;
+    asm volatile("" : "+v"(te));
+    if constexpr (KO == 9) {
+      MdmMlpDesc g2 = g;
+      g2.R2 = nullptr;
+      store_tile<HT, RT, NJ, G::SMEM, KO>(g2, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
+      XSTAMP(6);
+      if (te == 0) atomicAdd((unsigned long long*)g.R2 + 7, 1ull);
+    } else {
+      store_tile<HT, RT, NJ, G::SMEM, KO>(g, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
+    }
+    lds_barrier();  // the staging reads of this tile are done before the next tile's X rows land in the same LDS
   }
   if constexpr (KO == 9) {
     if (threadIdx.x == 0) {
@@ -572,32 +508,47 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_xres_kernel(const MdmMlpDesc 
   }
 }
 
-// ---- weight stream packing: fp32 / 16-bit row-major expert weights -> the per-(group, wave) fragment stream ------------
-// stream[g][wave w][chunk c][fragment f][lane l][8]:
-//   f <  2 Din/32 (phase 1):  step = f >> 1, j = f & 1:   W1[g][256 c + 32 w + 16 j + (l & 15)][32 step + 8 (l >> 4) + e]
-//   f >= 2 Din/32 (phase 2):  f' = f - 2 Din/32, s = f' / NJ, j = f' % NJ, hidden-image position p = 32 s + 8 (l >> 4) + e:
-//                                                         W2[g][16 NJ w + 16 j + (l & 15)][256 c + unit(p)]
-//   unit(p) = 32 ((p >> 4) & 7) + 16 (p >> 7) + (p & 15): the image holds, per half, the 16 units wave 0 produced for that
-//   half, then wave 1's, ... (the hidden chunk can then be published and consumed one half at a time)
+// ---- weight stream packing: fp32 row-major expert weights -> the per-(group, wave) fragment stream ----------------------
+// One fragment = 64 lanes x 8 elements: lane l holds row (l & 15), k = 8 (l >> 4) + e of a 16 x 32 block (the MFMA A operand).
+// With f1 = 2 Din/32 (phase-1 fragments per chunk), q = 4 NJ (phase-2 fragments per half), C = F / 256 chunks, the stream of
+// (group g, wave w) is, in this order:
+//     W1(0)  H0(0)  |  W1(1)  H1(0)  H0(1)  |  W1(2)  H1(1)  H0(2)  | ... |  W1(C-1)  H1(C-2)  H0(C-1)  |  H1(C-1)
+//   W1(c), fragment f: step = f >> 1, j = f & 1:   W1[g][256 c + 32 w + 16 j + (l & 15)][32 step + 8 (l >> 4) + e]
+//   Hh(c), fragment f: s = f / NJ, j = f % NJ, hidden-image position p = 32 s + 8 (l >> 4) + e of half h:
+//                                                   W2[g][16 NJ w + 16 j + (l & 15)][256 c + 32 (p >> 4) + 16 h + (p & 15)]
+//   (the half image holds the 16 units wave 0 produced for that half, then wave 1's, ...: unit 32 w' + 16 h + u at position
+//   16 w' + u)
 template <typename HT>
 __global__ __launch_bounds__(256) void mlp_stream_pack_kernel(const float* w1, const float* w2, int G, int F, int Din, int Dout,
                                                               uint16_t* out) {
-  const int NJ = Dout / 128, nchunk = F / FC, f1 = 2 * (Din / 32), fpc = f1 + 8 * NJ;
+  const int NJ = Dout / 128, nchunk = F / FC, f1 = 2 * (Din / 32), q = 4 * NJ, fpc = f1 + 2 * q;
   const int64_t nfrag = (int64_t)G * 8 * nchunk * fpc;
   for (int64_t fi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); fi < nfrag; fi += (int64_t)gridDim.x * 4) {
     const int l = threadIdx.x & 63;
-    const int f = (int)(fi % fpc);
-    const int c = (int)((fi / fpc) % nchunk);
-    const int w = (int)((fi / fpc / nchunk) % 8);
-    const int gi = (int)(fi / fpc / nchunk / 8);
+    const int f = (int)(fi % ((int64_t)nchunk * fpc));  // position in the wave's stream
+    const int w = (int)((fi / ((int64_t)nchunk * fpc)) % 8);
+    const int gi = (int)(fi / ((int64_t)nchunk * fpc) / 8);
+    int c, loc;  // block (chunk) and position inside it
+    if (f < f1 + q) {
+      c = 0, loc = f;
+    } else {
+      c = 1 + (f - (f1 + q)) / fpc, loc = (f - (f1 + q)) % fpc;
+    }
     const float* src;
-    if (f < f1) {
-      const int step = f >> 1, j = f & 1;
+    int hh = -1, cc = c, fp = 0;  // phase-2 fragment: half, chunk, index in the half
+    if (c == nchunk) {
+      hh = 1, cc = nchunk - 1, fp = loc;  // the tail H1(C-1)
+    } else if (loc >= f1) {
+      if (c == 0) hh = 0, fp = loc - f1;
+      else if (loc < f1 + q) hh = 1, cc = c - 1, fp = loc - f1;
+      else hh = 0, fp = loc - f1 - q;
+    }
+    if (hh < 0) {
+      const int step = loc >> 1, j = loc & 1;
       src = w1 + ((int64_t)gi * F + 256 * c + 32 * w + 16 * j + (l & 15)) * Din + 32 * step + 8 * (l >> 4);
     } else {
-      const int fp = f - f1, s = fp / NJ, j = fp % NJ;
-      const int kp = 32 * s + 8 * (l >> 4);  // position in the hidden image: half kp >> 7, wave (kp >> 4) & 7, unit kp & 15 (+ e)
-      src = w2 + ((int64_t)gi * Dout + 16 * NJ * w + 16 * j + (l & 15)) * F + 256 * c + 32 * ((kp >> 4) & 7) + 16 * (kp >> 7) + (kp & 15);
+      const int s = fp / NJ, j = fp % NJ, p = 32 * s + 8 * (l >> 4);
+      src = w2 + ((int64_t)gi * Dout + 16 * NJ * w + 16 * j + (l & 15)) * F + 256 * cc + 32 * (p >> 4) + 16 * hh + (p & 15);
     }
     uint4 o;
     o.x = HT::pack(src[0], src[1]), o.y = HT::pack(src[2], src[3]), o.z = HT::pack(src[4], src[5]), o.w = HT::pack(src[6], src[7]);
@@ -624,7 +575,7 @@ int64_t mlp_stream_elems(int G, int F, int Din, int Dout) {
 }
 
 int mlp_stream_pack(const float* w1, const float* w2, int G, int F, int Din, int Dout, int h16, uint16_t* out, hipStream_t stream) {
-  if (!w1 || !w2 || !out || G < 1 || (F % FC) || (Din % 128) || (Dout != 512 && Dout != 1024)) return MDM_ERR_UNSUPPORTED;
+  if (!w1 || !w2 || !out || G < 1 || F < FC || (F % FC) || Din < 128 || (Din % 128) || (Dout != 512 && Dout != 1024)) return MDM_ERR_UNSUPPORTED;
   const int64_t body = (int64_t)G * ((int64_t)F * Din + (int64_t)Dout * F);
   if (hipMemsetAsync(out + body, 0, 8 * 512 * sizeof(uint16_t), stream) != hipSuccess) return MDM_ERR_LAUNCH;
   const int blocks = (int)((body / 512 + 3) / 4 < 4096 ? (body / 512 + 3) / 4 : 4096);
@@ -638,7 +589,7 @@ int mlp_stream_pack(const float* w1, const float* w2, int G, int F, int Din, int
 }
 
 bool fused_mlp_stream_supported(const MdmMlpDesc& a) {
-  if (!a.wstream || a.Dout != 512 || a.Din < 128 || (a.Din % 128) || a.F < FC || (a.F % FC) || a.M < 1) return false;
+  if (!a.wstream || a.Dout != 512 || (a.Din != 128 && a.Din != 256 && a.Din != 512) || a.F < FC || (a.F % FC) || a.M < 1) return false;
   if (a.goff && (a.ngroups < 1 || a.ngroups > 64)) return false;
   if ((a.ldx % 8) || ((((uintptr_t)a.X) | ((uintptr_t)a.wstream)) & 15) || (a.wstream_gs % 8)) return false;
   if ((a.ldc & 3) || (a.R1 && (a.ldr1 & 3)) || (a.R2 && (a.ldr2 & 3))) return false;
@@ -647,7 +598,7 @@ bool fused_mlp_stream_supported(const MdmMlpDesc& a) {
 }
 
 // tile height: the tiles of all groups should fill the CUs in whole rounds
-int mlp_stream_tile_h(int64_t M, int ngroups, int rt_max) {
+int mlp_stream_tile_h(int64_t M, int rt_max) {
   const int cus = device_cus();
   const int64_t cap = (int64_t)cus * rt_max * 16;
   const int64_t rounds = (M + cap - 1) / cap;
@@ -655,47 +606,29 @@ int mlp_stream_tile_h(int64_t M, int ngroups, int rt_max) {
   h = (h + 15) & ~15ll;
   if (h < 16) h = 16;
   if (h > rt_max * 16) h = rt_max * 16;
-  (void)ngroups;
   return (int)h;
 }
 
 extern int g_bf16_variant;
 
-template <int KO>
+template <int DIN, int KO>
 static int launch_stream(const MdmMlpDesc& a, hipStream_t stream) {
   constexpr int RT = 7, NJ = 4;
-  const int th = mlp_stream_tile_h(a.M, a.goff ? a.ngroups : 1, RT);
-  const int tiles = (int)(a.M / th) + (a.goff ? a.ngroups : 1);
-  if (a.Din == 512 && g_bf16_variant != 40) {  // X rows resident in LDS (knob 40: the staged-X form, for A/B runs)
-    constexpr int smem = XGeo<RT, 512>::SMEM;
-    static DevOnce attr;
-    if (!attr) {
-      if (hipFuncSetAttribute((const void*)fused_mlp_xres_kernel<HB, RT, NJ, 512, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-          hipFuncSetAttribute((const void*)fused_mlp_xres_kernel<HF, RT, NJ, 512, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-        return MDM_ERR_LAUNCH;
-      attr = true;
-    }
-    const int grid = tiles < device_cus() ? tiles : device_cus();  // persistent: one workgroup per CU walks the tiles
-    if (a.h16 == MDM_H16_F16) {
-      hipLaunchKernelGGL((fused_mlp_xres_kernel<HF, RT, NJ, 512, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
-    } else {
-      hipLaunchKernelGGL((fused_mlp_xres_kernel<HB, RT, NJ, 512, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
-    }
-    MDM_RETURN_IF_LAUNCH_FAILED();
-    return MDM_OK;
-  }
-  constexpr int smem = SGeo<RT>::SMEM;
+  constexpr int smem = XGeo<RT, DIN>::SMEM;
   static DevOnce attr;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)fused_mlp_stream_kernel<HB, RT, NJ, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-        hipFuncSetAttribute((const void*)fused_mlp_stream_kernel<HF, RT, NJ, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+  if (smem > 65536 && !attr) {
+    if (hipFuncSetAttribute((const void*)fused_mlp_stream_kernel<HB, RT, NJ, DIN, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)fused_mlp_stream_kernel<HF, RT, NJ, DIN, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr = true;
   }
+  const int th = mlp_stream_tile_h(a.M, RT);
+  const int tiles = (int)(a.M / th) + (a.goff ? a.ngroups : 1);  // upper bound of the tile count
+  const int grid = tiles < device_cus() ? tiles : device_cus();  // persistent: one workgroup per CU walks the tiles
   if (a.h16 == MDM_H16_F16) {
-    hipLaunchKernelGGL((fused_mlp_stream_kernel<HF, RT, NJ, KO>), dim3(tiles), dim3(NT), smem, stream, a, th);
+    hipLaunchKernelGGL((fused_mlp_stream_kernel<HF, RT, NJ, DIN, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
   } else {
-    hipLaunchKernelGGL((fused_mlp_stream_kernel<HB, RT, NJ, KO>), dim3(tiles), dim3(NT), smem, stream, a, th);
+    hipLaunchKernelGGL((fused_mlp_stream_kernel<HB, RT, NJ, DIN, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
@@ -704,17 +637,19 @@ static int launch_stream(const MdmMlpDesc& a, hipStream_t stream) {
 int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream) {
   if (!a.X || (!a.C && !a.C16)) return MDM_ERR_ARG;
   if (!fused_mlp_stream_supported(a)) return MDM_ERR_UNSUPPORTED;
-  switch (g_bf16_variant) {  // knobs 41..46: knock-out builds; 47: erf-form GELU (bit-identical to csrc/mlp.hip) for tools/mlp_bench.py (wrong results, timing only)
-    case 41: return launch_stream<1>(a, stream);
-    case 42: return launch_stream<2>(a, stream);
-    case 43: return launch_stream<3>(a, stream);
-    case 44: return launch_stream<4>(a, stream);
-    case 45: return launch_stream<5>(a, stream);
-    case 46: return launch_stream<6>(a, stream);
-    case 47: return launch_stream<7>(a, stream);
-    case 48: return launch_stream<8>(a, stream);
-    case 49: return launch_stream<9>(a, stream);
-    default: return launch_stream<0>(a, stream);
+  if (a.Din == 128) return launch_stream<128, 0>(a, stream);
+  if (a.Din == 256) return launch_stream<256, 0>(a, stream);
+  switch (g_bf16_variant) {  // knobs 41..49: knock-out / diagnostic builds for tools/mlp_ko.py, tools/mlp_stamps.py (timing only)
+    case 41: return launch_stream<512, 1>(a, stream);
+    case 42: return launch_stream<512, 2>(a, stream);
+    case 43: return launch_stream<512, 3>(a, stream);
+    case 44: return launch_stream<512, 4>(a, stream);
+    case 45: return launch_stream<512, 5>(a, stream);
+    case 46: return launch_stream<512, 6>(a, stream);
+    case 47: return launch_stream<512, 7>(a, stream);
+    case 48: return launch_stream<512, 8>(a, stream);
+    case 49: return launch_stream<512, 9>(a, stream);
+    default: return launch_stream<512, 0>(a, stream);
   }
 }
 

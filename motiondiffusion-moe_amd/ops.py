@@ -183,17 +183,27 @@ def mlp_stream_pack(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype) -> t
 
 
 def mlp_stream_pack_reference(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """The same layout written as torch reshapes (tests check the packer kernel against it)."""
+    """The same layout written as torch reshapes (tests check the packer kernel against it); csrc/mlp_stream.hip documents
+    the order: per (group, wave)  W1(0) H0(0) | W1(1) H1(0) H0(1) | ... | W1(C-1) H1(C-2) H0(C-1) | H1(C-1)."""
     if w1.dim() == 2:
         w1, w2 = w1[None], w2[None]
     G, F, Din = w1.shape
     Dout = w2.shape[1]
     NJ, Cn, KT = Dout // 128, F // 256, Din // 32
-    a = w1.reshape(G, Cn, 8, 2, 16, KT, 4, 8).permute(0, 2, 1, 5, 3, 6, 4, 7)      # g, w, c, step, j, q, r, e
-    # hidden-image position p = 128 h + 16 w' + u holds unit 32 w' + 16 h + u of the chunk: reorder w2's k axis to p first
-    w2p = w2.reshape(G, Dout, Cn, 8, 2, 16).permute(0, 1, 2, 4, 3, 5).reshape(G, Dout, F)      # (.., w', h, u) -> (.., h, w', u)
-    b = w2p.reshape(G, 8, NJ, 16, Cn, 8, 4, 8).permute(0, 1, 4, 5, 2, 6, 3, 7)     # g, w, c, s, j, q, r, e
-    s = torch.cat([a.reshape(G, 8, Cn, -1), b.reshape(G, 8, Cn, -1)], dim=3).to(dtype).reshape(-1)
+    # W1 fragments: [g, w, c, step, j, lane = (q, r), e]
+    a = w1.reshape(G, Cn, 8, 2, 16, KT, 4, 8).permute(0, 2, 1, 5, 3, 6, 4, 7).reshape(G, 8, Cn, -1)
+    # hidden-image position p = 16 w' + u of half h holds unit 32 w' + 16 h + u of the chunk: reorder w2's k axis to (c, h, p)
+    w2p = w2.reshape(G, Dout, Cn, 8, 2, 16).permute(0, 1, 2, 4, 3, 5).reshape(G, Dout, Cn, 2, 128)
+    # phase-2 fragments of one half: [g, w, c, h, s, j, lane = (q, r), e]
+    b = w2p.reshape(G, 8, NJ, 16, Cn, 2, 4, 4, 8).permute(0, 1, 4, 5, 6, 2, 7, 3, 8).reshape(G, 8, Cn, 2, -1)
+    parts = []
+    for c in range(Cn):
+        parts.append(a[:, :, c])
+        if c > 0:
+            parts.append(b[:, :, c - 1, 1])
+        parts.append(b[:, :, c, 0])
+    parts.append(b[:, :, Cn - 1, 1])
+    s = torch.cat(parts, dim=2).to(dtype).reshape(-1)
     return torch.cat([s, torch.zeros(8 * 512, dtype=dtype, device=s.device)])
 
 

@@ -91,7 +91,7 @@ def test_weight_stream_packer_matches_the_documented_layout():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("sizes,F,Din", [([130, 0, 257, 1, 128], 1024, 512), ([3136] * 4, 1024, 512), ([64, 700], 256, 128),
-                                         ([113, 111, 112, 225, 17], 512, 256)])
+                                         ([113, 111, 112, 225, 17], 512, 256), ([300], 768, 512)])
 def test_streamed_weight_kernel(dtype, sizes, F, Din):
     """Streamed-weight fused expert MLP (csrc/mlp_stream.hip: weights global -> registers from the packed fragment stream,
     balanced tiles): grouped / gathered / ragged / empty groups, both 16-bit formats, fp32 and 16-bit outputs, against the
@@ -126,7 +126,7 @@ def test_streamed_weight_kernel(dtype, sizes, F, Din):
     e32 = rel_inf(out[:M].cpu(), ref.float().cpu())
     e16 = rel_inf(out16[:M].float().cpu(), ref.float().cpu())
     d = None
-    if Din % 64 == 0:
+    if True:
         old = torch.empty((M, Dout), device="cuda")
         L.lib().mdm_set_gemm_variant(34)  # the LDS-staged kernel of csrc/mlp.hip
         try:
