@@ -15,12 +15,13 @@
 //     per (group, wave) in exactly the order the wave consumes them (mdm_mlp_stream_pack), they go global -> registers with
 //     plain 16-byte loads through an 8-fragment register ring that runs 8 fragments (~0.9 k MFMA cycles) ahead.  No LDS-DMA,
 //     no barrier and no LDS read for 94 % of the bytes a tile moves.
-//   * the GELU (VALU) runs UNDER phase-2 MFMAs of the same wave: the order of a chunk is
-//         phase 1 (c)  ->  { phase 2, second half of chunk c - 1 }  with  GELU of half 0 of chunk c  interleaved
-//         -> publish half 0 ->  { phase 2, first half of chunk c }  with  GELU of half 1 of chunk c  interleaved  -> publish half 1
-//     (per { 4 MFMAs, 1 fragment read } one half of a value pair's GELU: ~2 VALU instructions per MFMA, what an MFMA's issue
-//     shadow holds); done back to back, the GELU of a chunk is 4.7 k cycles of every SIMD with its matrix pipe idle (15 % of a tile).
-//   * every { MFMAs of one A fragment, 1 fragment read, GELU piece } is pinned by a scheduling barrier, the A fragments go
+//   * the order of a chunk is  phase 1 (c) -> phase 2, second half of chunk c - 1 -> GELU half 0 -> publish -> phase 2, first
+//     half of chunk c -> GELU half 1 -> publish.  The GELU is x * sigmoid(q(x)) on SCALAR fp32 instructions (beside MFMAs a
+//     packed-fp32 instruction costs several plain ones; this file is compiled with -fno-slp-vectorize).  Interleaving its
+//     pieces with the phase-2 MFMAs of the same wave (knob 48) measured 1.5 % slower than back to back, storing the 16-bit
+//     outputs straight from the accumulators 3 % slower than staging full rows through LDS, requesting the next tile's X rows
+//     between the two halves of the epilogue 4 % slower (the wait moves, it does not shrink): all three tried and dropped.
+//   * every { MFMAs of one A fragment, 1 fragment read } is pinned by a scheduling barrier, the A fragments go
 //     through a small register ring that runs ahead of the MFMAs: left alone hipcc sinks the weight refills of an unrolled
 //     body to its end (the ring's run-ahead collapses) and, once registers are tight, reads one fragment, waits, issues its
 //     MFMAs (one exposed LDS round trip per 32 MFMA cycles).
@@ -90,20 +91,6 @@ __device__ __forceinline__ void store_tile(const MdmMlpDesc& g, f32x4 (&y)[RT][N
     // 16-bit output only (the expert MLPs of the throughput modes): the whole tile staged once as 16-bit [rows][DOUT], one
     // wave-instruction stores one full row (64 lanes x 16 B)
     constexpr int ROWB = DOUT * 2, CH = ROWB / 16;  // 16-B chunks per row
-    if constexpr (KO == 3) {  // knob 43: straight from the accumulators, 8 bytes per lane (16 rows x 32 B per instruction)
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int m = row0 + i * 16 + frow;
-        const float rs = g.rowscale ? g.rowscale[m < row_end ? m : row_end - 1] : 1.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int n = wn * (16 * NJ) + 16 * j + 4 * fq;
-          const f32x4 v = y[i][j];
-          if (m < row_end) *(uint2*)(g.C16 + (int64_t)m * g.ldc + n) = make_uint2(HT::pack(v[0] * rs, v[1] * rs), HT::pack(v[2] * rs, v[3] * rs));
-        }
-      }
-      return;
-    }
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
@@ -232,8 +219,8 @@ __device__ __forceinline__ f32x2 gelu_part_b(f32x2 v, f32x2 e) {
 }
 
 // KO: timing-only knock-outs for tools/mlp_ko.py (0 = the real kernel; results are wrong otherwise): 1 no GELU arithmetic,
-// 2 no weight refills, 3 = real kernel with the 16-bit outputs stored straight from the accumulators, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores; 7 = the real kernel with the erf-form GELU
-// of the LDS-staged kernel (not interleaved); 8 = GELU not interleaved (back to back before the publish); 9 = stamped build
+// 2 no weight refills, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores; 7 = the real kernel with the erf-form GELU
+// of the LDS-staged kernel; 8 = GELU pieces interleaved with the phase-2 MFMAs of the same wave; 9 = stamped build
 template <typename HT, int RT, int NJ, int DIN, int KO>
 __global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h) {
   typedef typename HT::frag_t frag_t;
@@ -241,7 +228,7 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDes
   constexpr int NKO = DIN / 128, NLINE = DIN / 64;
   constexpr int NA = 4, PD = NA - 1;  // A-fragment ring: NA registers, PD fragments ahead of the MFMAs
   constexpr int NF = 4 * RT;          // A fragments per unrolled body (4 K steps x RT row tiles)
-  constexpr bool ILV = KO != 7 && KO != 8;  // GELU pieces interleaved with phase-2 MFMAs
+  constexpr bool ILV = KO == 8;  // knob 48: GELU pieces interleaved with phase-2 MFMAs (measured 1.5 % SLOWER than back to back)
   static_assert(NF % NA == 0, "the ring must close over the unrolled body");
   static_assert(NF >= 4 * RT, "one GELU pair piece per fragment: 2 RT pairs x 2 pieces");
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
@@ -642,7 +629,6 @@ int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream) {
   switch (g_bf16_variant) {  // knobs 41..49: knock-out / diagnostic builds for tools/mlp_ko.py, tools/mlp_stamps.py (timing only)
     case 41: return launch_stream<512, 1>(a, stream);
     case 42: return launch_stream<512, 2>(a, stream);
-    case 43: return launch_stream<512, 3>(a, stream);
     case 44: return launch_stream<512, 4>(a, stream);
     case 45: return launch_stream<512, 5>(a, stream);
     case 46: return launch_stream<512, 6>(a, stream);

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("motiondiffusion-moe_amd.ops")
 L = importlib.import_module("motiondiffusion-moe_amd._lib")
 
-NAMES = {0: "full", 34: "lds-staged kernel", 41: "no GELU arithmetic", 42: "no weight refills", 43: "direct 16-bit stores",          44: "no phase-1 MFMA", 45: "no phase-2 MFMA", 46: "no output stores", 47: "erf-form GELU, not interleaved", 48: "GELU not interleaved"}
+NAMES = {0: "full", 34: "lds-staged kernel", 41: "no GELU arithmetic", 42: "no weight refills",           44: "no phase-1 MFMA", 45: "no phase-2 MFMA", 46: "no output stores", 47: "erf-form GELU", 48: "GELU interleaved with MFMAs"}
 
 
 def timeit(fn, n=20):
