@@ -138,6 +138,10 @@ int mdm_fused_mlp(const MdmMlpDesc* desc, void* stream);
 int64_t mdm_mlp_stream_elems(int32_t G, int32_t F, int32_t Din, int32_t Dout);
 int mdm_mlp_stream_pack(const float* w1, const float* w2, int32_t G, int32_t F, int32_t Din, int32_t Dout, int32_t h16,
                         uint16_t* out, void* stream);
+/* Weight stream of ONE Linear [N, K] fp32 for the fused stylization kernel (csrc/style_gemm.hip; N = K = 512): elements
+ * the buffer needs (0 = shape not taken) and the packer. */
+int64_t mdm_gemm_stream_elems(int32_t N, int32_t K);
+int mdm_gemm_stream_pack(const float* w, int32_t N, int32_t K, int32_t h16, uint16_t* out, void* stream);
 
 /* fp32 [rows, K] (row stride ld_src) -> bf16 planes [rows, Kpad] (Kpad = ld_dst, multiple of 32, zero padded);
  * lo may be NULL.  Weight packing happens once at load time (not on the hot path). */
@@ -160,6 +164,7 @@ typedef struct MdmStyle { /* StylizationBlock minus its emb_layers (those are st
   const float *norm_w, *norm_b;
   MdmPacked out; /* out_layers.2 [D,D] */
   const float* out_b;
+  const uint16_t* out_ws; /* optional weight stream of out_layers.2 (mdm_gemm_stream_pack; 16-bit modes, D == 512), or NULL */
 } MdmStyle;
 
 typedef struct MdmPerformer { /* PerformerSelfAttention, fast_attention.py:94-179 */
@@ -170,6 +175,7 @@ typedef struct MdmPerformer { /* PerformerSelfAttention, fast_attention.py:94-17
   MdmPacked feat;           /* projection_matrix^T [m, dh] (captured random state, fast_attention.py:19-36) */
   MdmPacked proj0, proj3;
   const float *proj0_b, *proj3_b;
+  const uint16_t* proj_ws; /* optional weight stream of proj_out.0 / proj_out.3 (mdm_mlp_stream_pack, G = 1), or NULL */
   MdmStyle style;
 } MdmPerformer;
 
@@ -198,6 +204,7 @@ typedef struct MdmLayer { /* MoEExtendedDecoderLayer, transformer.py:17-64 */
   const float *sd_q_b, *sd_k_b, *sd_v_b, *sd_out_b, *sd_ln_w, *sd_ln_b, *sd_f1_b, *sd_f2_b;
   /* optional fp32 copies of sd_cross_attn.query / .out weights [D, D]: needed only to build the folded text cache */
   const float *sd_q_w32, *sd_out_w32;
+  const uint16_t* sd_ffn_ws; /* optional weight stream of sd_cross_attn.ffn.1 / .3 (mdm_mlp_stream_pack, G = 1), or NULL */
 } MdmLayer;
 
 typedef struct MdmModel { /* MotionTransformer, transformer.py:166-361 */

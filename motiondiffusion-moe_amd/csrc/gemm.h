@@ -65,5 +65,12 @@ bool fused_mlp_stream_supported(const MdmMlpDesc& a);
 int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream);
 int64_t mlp_stream_elems(int G, int F, int Din, int Dout);
 int mlp_stream_pack(const float* w1, const float* w2, int G, int F, int Din, int Dout, int h16, uint16_t* out, hipStream_t stream);
+// style_gemm.hip: stylization input + its D x D Linear + the residual in one launch (streamed weights)
+int64_t gemm_stream_elems(int N, int K);
+int gemm_stream_pack(const float* w, int N, int K, int h16, uint16_t* out, hipStream_t stream);
+bool style_gemm_supported(int D, int64_t M);
+int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
+               const float* sc, const int* pos4, const uint16_t* ws, const float* bias, const float* resid, float out_scale,
+               const float* colscale, float* out, uint16_t* out16, int h16, hipStream_t s);
 
 }  // namespace mdm

@@ -197,7 +197,9 @@ struct XGeo {
   static constexpr int XROW_B = DIN * 2;     // X image: 16-B chunk c of row m at slot c ^ (m & 15)
   static constexpr int XIMG_B = ROWS * XROW_B;
   static constexpr int HID_B = ROWS * 256;   // half hidden chunk, 16-bit [ROWS][128]: chunk c of row m at slot c ^ (m & 15)
-  static constexpr int SMEM = XIMG_B + HID_B;
+  static constexpr int IMG_B = XIMG_B + HID_B;
+  static constexpr int STG_B = ROWS * 1024 > 32768 ? ROWS * 1024 : 32768;  // epilogue staging: the 16-bit tile, or one fp32 row tile (Dout 512)
+  static constexpr int SMEM = IMG_B > STG_B ? IMG_B : STG_B;
 };
 
 // The GELU of one value pair in two pieces (so that a piece fits beside the four MFMAs of one A fragment): gelu_sig2 of
@@ -222,7 +224,7 @@ __device__ __forceinline__ f32x2 gelu_part_b(f32x2 v, f32x2 e) {
 // 2 no weight refills, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores; 7 = the real kernel with the erf-form GELU
 // of the LDS-staged kernel; 8 = GELU pieces interleaved with the phase-2 MFMAs of the same wave; 9 = stamped build
 template <typename HT, int RT, int NJ, int DIN, int KO>
-__global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h) {
+__global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h) {
   typedef typename HT::frag_t frag_t;
   typedef XGeo<RT, DIN> G;
   constexpr int NKO = DIN / 128, NLINE = DIN / 64;
@@ -598,9 +600,9 @@ int mlp_stream_tile_h(int64_t M, int rt_max) {
 
 extern int g_bf16_variant;
 
-template <int DIN, int KO>
-static int launch_stream(const MdmMlpDesc& a, hipStream_t stream) {
-  constexpr int RT = 7, NJ = 4;
+template <int RT, int DIN, int KO>
+static int launch_stream(const MdmMlpDesc& a, int th, hipStream_t stream) {
+  constexpr int NJ = 4;
   constexpr int smem = XGeo<RT, DIN>::SMEM;
   static DevOnce attr;
   if (smem > 65536 && !attr) {
@@ -609,9 +611,10 @@ static int launch_stream(const MdmMlpDesc& a, hipStream_t stream) {
       return MDM_ERR_LAUNCH;
     attr = true;
   }
-  const int th = mlp_stream_tile_h(a.M, RT);
   const int tiles = (int)(a.M / th) + (a.goff ? a.ngroups : 1);  // upper bound of the tile count
-  const int grid = tiles < device_cus() ? tiles : device_cus();  // persistent: one workgroup per CU walks the tiles
+  // persistent: the resident workgroups (one per CU; two of the 32-row form: 128 registers, 40 KiB of LDS) walk the tiles
+  const int res = device_cus() * (RT <= 2 ? 2 : 1);
+  const int grid = tiles < res ? tiles : res;
   if (a.h16 == MDM_H16_F16) {
     hipLaunchKernelGGL((fused_mlp_stream_kernel<HF, RT, NJ, DIN, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
   } else {
@@ -621,22 +624,36 @@ static int launch_stream(const MdmMlpDesc& a, hipStream_t stream) {
   return MDM_OK;
 }
 
+// row tiles per workgroup by tile height: 32-row (RT 2) and 64-row (RT 4) forms for launches with few rows per CU (the dense
+// Linear-GELU-Linear pairs: 6272 / 12544 rows), 112-row form (RT 7) for the expert MLPs
+template <int DIN>
+static int launch_by_height(const MdmMlpDesc& a, hipStream_t stream) {
+  const int th = mlp_stream_tile_h(a.M, 7);
+  if (th <= 32) return launch_stream<2, DIN, 0>(a, th, stream);
+  if (th <= 64) return launch_stream<4, DIN, 0>(a, th, stream);
+  return launch_stream<7, DIN, 0>(a, th, stream);
+}
+
 int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream) {
   if (!a.X || (!a.C && !a.C16)) return MDM_ERR_ARG;
   if (!fused_mlp_stream_supported(a)) return MDM_ERR_UNSUPPORTED;
-  if (a.Din == 128) return launch_stream<128, 0>(a, stream);
-  if (a.Din == 256) return launch_stream<256, 0>(a, stream);
-  switch (g_bf16_variant) {  // knobs 41..49: knock-out / diagnostic builds for tools/mlp_ko.py, tools/mlp_stamps.py (timing only)
-    case 41: return launch_stream<512, 1>(a, stream);
-    case 42: return launch_stream<512, 2>(a, stream);
-    case 44: return launch_stream<512, 4>(a, stream);
-    case 45: return launch_stream<512, 5>(a, stream);
-    case 46: return launch_stream<512, 6>(a, stream);
-    case 47: return launch_stream<512, 7>(a, stream);
-    case 48: return launch_stream<512, 8>(a, stream);
-    case 49: return launch_stream<512, 9>(a, stream);
-    default: return launch_stream<512, 0>(a, stream);
+  if (a.Din == 128) return launch_by_height<128>(a, stream);
+  if (a.Din == 256) return launch_by_height<256>(a, stream);
+  const int th = mlp_stream_tile_h(a.M, 7);
+  if (th > 64) {
+    switch (g_bf16_variant) {  // knobs 41..49: knock-out / diagnostic builds for tools/mlp_ko.py, tools/mlp_stamps.py (timing only)
+      case 41: return launch_stream<7, 512, 1>(a, th, stream);
+      case 42: return launch_stream<7, 512, 2>(a, th, stream);
+      case 44: return launch_stream<7, 512, 4>(a, th, stream);
+      case 45: return launch_stream<7, 512, 5>(a, th, stream);
+      case 46: return launch_stream<7, 512, 6>(a, th, stream);
+      case 47: return launch_stream<7, 512, 7>(a, th, stream);
+      case 48: return launch_stream<7, 512, 8>(a, th, stream);
+      case 49: return launch_stream<7, 512, 9>(a, th, stream);
+      default: break;
+    }
   }
+  return launch_by_height<512>(a, stream);
 }
 
 }  // namespace mdm

@@ -184,6 +184,9 @@ int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float*
                 const float* sc, float* tmp, const float* resid, float out_scale, const float* colscale, float* out,
                 uint16_t* out16 = nullptr, bool src_bf16 = false) {
   const int D = c.m->D;
+  if (c.bf && st.out_ws && g_bf16_variant != 30 && style_gemm_supported(D, c.M))  // one launch (csrc/style_gemm.hip); knob 30: two
+    return style_gemm(src, src_bf16 ? c.h16 : 0, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, st.out_ws, st.out_b, resid,
+                      out_scale, colscale, out, out16, c.h16, c.s);
   MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, src_bf16 ? c.h16 : 0, tmp, fmt16(c), c.s));
   LinOpts o;
   o.out_scale = out_scale, o.R1 = resid, o.colscale = colscale;
@@ -256,13 +259,24 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     MDM_TRY(den_ln(w.t2, w.phi, c.M, H, dh, p.hn_w, p.hn_b, w.t4, fmt16(c), c.s));
   }
   // proj_out: Linear -> GELU -> Linear                             (:121-126,165)
-  {
+  const bool t16 = c.bf && g_bf16_variant != 25;  // the projection's output feeds a LayerNorm only: bf16 in throughput mode
+  bool pair = false;
+  if (t16 && p.proj_ws && g_bf16_variant != 32) {  // one launch, hidden layer on chip (csrc/mlp_stream.hip); knob 32: two GEMMs
+    MdmMlpDesc f = {};
+    f.X = (const uint16_t*)w.t4, f.ldx = D, f.M = (int)c.M, f.Din = D, f.F = D, f.Dout = D;
+    f.b1 = p.proj0_b, f.b2 = p.proj3_b, f.wstream = p.proj_ws, f.wstream_gs = 2 * (int64_t)D * D;
+    f.r1_scale = 1.f, f.C16 = (uint16_t*)w.t4, f.ldc = D, f.h16 = c.h16;  // in place: a tile's rows are in LDS before its stores
+    if (fused_mlp_stream_supported(f)) {
+      MDM_TRY(fused_mlp_stream(f, c.s));
+      pair = true;
+    }
+  }
+  if (!pair) {
     LinOpts o;
     o.act = ACT_GELU;
     MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, p.proj0, p.proj0_b, D, w.t2, o));
+    MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, p.proj3, p.proj3_b, D, t16 ? nullptr : w.t4, t16 ? (uint16_t*)w.t4 : nullptr));
   }
-  const bool t16 = c.bf && g_bf16_variant != 25;  // the projection's output feeds a LayerNorm only: bf16 in throughput mode
-  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, p.proj3, p.proj3_b, D, t16 ? nullptr : w.t4, t16 ? (uint16_t*)w.t4 : nullptr));
   // post_norm, normalize * sqrt(D), stylization, y = x + 0.1 * style (:169-178)
   return style_apply(c, p.style, w.t4, p.post_w, p.post_b, nullptr, sc, w.t2, x, 0.1f, nullptr, out, nullptr, t16);
 }
@@ -453,6 +467,14 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
     // throughput mode: query GEMM + attention core + output GEMM + LayerNorm in one launch (csrc/sdfold.hip)
     MDM_TRY(sd_fold(x16, fold.kfold, fold.cb, fold.vfold, l.sd_out_b, l.sd_ln_w, l.sd_ln_b, c.B, c.S, D, H, N, w.t3,
                     (uint16_t*)w.t4, c.h16, c.s));
+    if (l.sd_ffn_ws && g_bf16_variant != 33) {  // the 4x FFN pair in one launch (knob 33: two GEMMs)
+      MdmMlpDesc f = {};
+      f.X = (const uint16_t*)w.t4, f.ldx = D, f.M = (int)c.M, f.Din = D, f.F = 4 * D, f.Dout = D;
+      f.b1 = l.sd_f1_b, f.b2 = l.sd_f2_b, f.wstream = l.sd_ffn_ws, f.wstream_gs = 8 * (int64_t)D * D;
+      f.R1 = x, f.ldr1 = D, f.r1_scale = 1.f, f.R2 = w.t3, f.ldr2 = D;  // x + (o + ffn(o))
+      f.C = out, f.C16 = out16, f.ldc = D, f.h16 = c.h16;
+      if (fused_mlp_stream_supported(f)) return fused_mlp_stream(f, c.s);
+    }
     LinOpts o1;
     o1.act = ACT_GELU;
     MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, w.f1, o1));

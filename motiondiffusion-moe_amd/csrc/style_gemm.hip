@@ -1,0 +1,253 @@
+// StylizationBlock in ONE launch (stylization.py:20-31 behind its callers' row-wise heads):
+//     s   = SiLU( LN_style(a) * (1 + scale[b]) + shift[b] )                       a per row, as csrc/rowwise.hip style_in:
+//           a = x | normalize(LN_post(x)) * sqrt(D) (Performer tail, fast_attention.py:169-172) | 0.5 * sum of the token's four
+//           routed expert rows (MoE combine, switch_moe.py:109 + multi_branch.py:58-59)
+//     out = resid + out_scale * colscale * ( s Wout^T + b )                        (out_layers.2 and the caller's residual)
+// replaces the style_in launch + the D x D GEMM launch behind it (4 pairs per decoder layer, 32 per forward) and the 16-bit
+// [M, D] tensor between them.  D = 512, 16-bit modes.
+//
+// One workgroup (8 waves, <= 128 registers: two resident per CU) owns 32 whole rows:
+//   * row phase: wave w brings rows 4 w .. 4 w + 3 exactly as the row-wise kernel does (one wave per row, DPP reductions) and
+//     leaves them as 16-bit MFMA rows in a 32-KiB LDS image (16-B chunk c of row r at slot c ^ (r & 15));
+//   * GEMM phase: wave w owns output columns [64 w, 64 w + 64): the image is the shared operand, Wout is streamed global ->
+//     registers from a packed fragment stream (mdm_gemm_stream_pack: per wave the 64 fragments of its columns in K order) through
+//     an 8-fragment ring, as in csrc/mlp_stream.hip.  With 32 rows a weight fragment feeds only two MFMAs, so the launch is bound
+//     by the 512 KiB of Wout every workgroup streams (98 / 196 MB per launch, L2-resident), not by the matrix pipe;
+//   * epilogue: staged as fp32 rows through LDS, full-row stores, residual read coalesced.
+#include "gemm.h"
+#include "kernels.h"
+#include "row.h"
+
+namespace mdm {
+namespace {
+
+constexpr int SG_NT = 512, SG_D = 512, SG_ROWS = 32, SG_RT = 2, SG_NJ = 4;
+constexpr int SG_IMG_B = SG_ROWS * SG_D * 2;       // 32 KiB
+constexpr int SG_SMEM = SG_ROWS * SG_D * 4;        // 64 KiB: the fp32 staging of the epilogue covers the image
+
+__device__ __forceinline__ void sg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+struct StyleGemmArgs {
+  const void* src;      // fp32 [*, D] or 16-bit rows (format of the launch)
+  int64_t M;
+  int S;                // frames per sample: row m belongs to sample m / S
+  const float *pw, *pb; // optional post_norm (+ L2 normalisation * sqrt(D))
+  const float *sw, *sb; // style norm
+  const float* sc;      // (B, 2 D) scale | shift
+  const int* pos4;      // optional (M, 4): the row is 0.5 * the sum of these four source rows
+  const uint16_t* ws;   // weight stream of out_layers.2
+  const float* bias;
+  const float* resid;   // optional [M, D]
+  float out_scale;
+  const float* colscale;  // optional [D]
+  float* out;
+  uint16_t* out16;      // optional 16-bit copy
+};
+
+template <typename HT, bool SRC16>
+__global__ __launch_bounds__(SG_NT, 4) void style_gemm_kernel(const StyleGemmArgs g) {
+  typedef typename HT::frag_t frag_t;
+  typedef Row<8, true> R8;
+  constexpr int D = SG_D, FMT = HT::FMT;
+  extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * SG_ROWS;
+
+  // the wave's weight stream: 64 fragments of 1 KiB; the ring's first 8 are requested before the row phase
+  const uint8_t* wp = (const uint8_t*)g.ws + (int64_t)wn * 64 * 1024 + lane * 16;
+  frag_t R[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) R[f] = *(const frag_t*)(wp + f * 1024);
+  wp += 8192;
+
+  // ---- row phase (csrc/rowwise.hip style_in_rows, one wave per row) ------------------------------------------------------
+  {
+    R8 pww, pbb, sww, sbb;
+    if (g.pw) pww.load(g.pw, D, lane), pbb.load(g.pb, D, lane);
+    sww.load(g.sw, D, lane), sbb.load(g.sb, D, lane);
+#pragma unroll 2
+    for (int q = 0; q < 4; ++q) {
+      const int rl = 4 * wn + q;
+      int64_t row = row0 + rl;
+      row = row < g.M ? row : g.M - 1;  // rows past the end: recomputed copies of the last row, never stored
+      const float* scb = g.sc + (row / g.S) * 2 * (int64_t)D;
+      R8 r, scale, shift;
+      scale.load(scb, D, lane);
+      shift.load(scb + D, D, lane);
+      if (g.pos4) {
+        const int p0 = g.pos4[row * 4 + 0], p1 = g.pos4[row * 4 + 1], p2 = g.pos4[row * 4 + 2], p3 = g.pos4[row * 4 + 3];
+        R8 a, b, c, d;
+        if constexpr (SRC16) {
+          const uint16_t* xh = (const uint16_t*)g.src;
+          a.template load_h16<FMT>(xh + (int64_t)p0 * D, D, lane);
+          b.template load_h16<FMT>(xh + (int64_t)p1 * D, D, lane);
+          c.template load_h16<FMT>(xh + (int64_t)p2 * D, D, lane);
+          d.template load_h16<FMT>(xh + (int64_t)p3 * D, D, lane);
+        } else {
+          const float* x = (const float*)g.src;
+          a.load(x + (int64_t)p0 * D, D, lane);
+          b.load(x + (int64_t)p1 * D, D, lane);
+          c.load(x + (int64_t)p2 * D, D, lane);
+          d.load(x + (int64_t)p3 * D, D, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.e[j] = ((a.e[j] + b.e[j]) + (c.e[j] + d.e[j])) * 0.5f;
+      } else {
+        if constexpr (SRC16) {
+          r.template load_h16<FMT>((const uint16_t*)g.src + row * D, D, lane);
+        } else {
+          r.load((const float*)g.src + row * D, D, lane);
+        }
+      }
+      if (g.pw) {
+        r.layernorm(pww, pbb, D, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += r.e[j] * r.e[j];
+        const float inv = sqrtf((float)D) / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.e[j] *= inv;
+      }
+      r.layernorm(sww, sbb, D, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.e[j] = silu(r.e[j] * (1.f + scale.e[j]) + shift.e[j]);
+      // lane holds columns 4 l .. 4 l + 3 and 256 + 4 l ..: 8 bytes each, 16-B chunks (l >> 1) and 32 + (l >> 1), half l & 1
+      uint8_t* ir = smem + rl * 1024 + (lane & 1) * 8;
+      *(uint2*)(ir + ((((lane >> 1)) ^ (rl & 15)) << 4)) = make_uint2(HT::pack(r.e[0], r.e[1]), HT::pack(r.e[2], r.e[3]));
+      *(uint2*)(ir + (((32 + (lane >> 1)) ^ (rl & 15)) << 4)) = make_uint2(HT::pack(r.e[4], r.e[5]), HT::pack(r.e[6], r.e[7]));
+    }
+  }
+  sg_barrier();
+
+  // ---- GEMM phase: y[32 rows x 64 columns of this wave] = image . Wout^T ---------------------------------------------------
+  const int frow = lane & 15, fq = lane >> 4;
+  f32x4 y[SG_RT][SG_NJ];
+#pragma unroll
+  for (int i = 0; i < SG_RT; ++i)
+#pragma unroll
+    for (int j = 0; j < SG_NJ; ++j) y[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const int xb = frow * 1024 + ((fq ^ frow) << 4);  // (row frow, K step 0); step s reads chunk (4 s) ^ (fq ^ frow)
+    frag_t A[2][SG_RT];
+#pragma unroll
+    for (int i = 0; i < SG_RT; ++i) A[0][i] = *(const frag_t*)(smem + xb + i * 16384);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) {
+#pragma unroll
+        for (int i = 0; i < SG_RT; ++i) A[(s + 1) & 1][i] = *(const frag_t*)(smem + (xb ^ (64 * ((s + 1) & 3))) + ((s + 1) >> 2) * 256 + i * 16384);
+      }
+#pragma unroll
+      for (int j = 0; j < SG_NJ; ++j) {
+        const int slot = (s * SG_NJ + j) & 7;
+#pragma unroll
+        for (int i = 0; i < SG_RT; ++i) y[i][j] = HT::mfma16(R[slot], A[s & 1][i], y[i][j]);
+        R[slot] = *(const frag_t*)(wp + slot * 1024);  // the last 8 refills read (and discard) the next wave's / the padding
+        if (slot == 7) wp += 8192;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: (y + b) * out_scale * colscale staged as fp32 [32][512], full rows out with the residual -----------------
+  sg_barrier();
+  float* stg = (float*)smem;
+#pragma unroll
+  for (int j = 0; j < SG_NJ; ++j) {
+    const int n = wn * 64 + 16 * j + 4 * fq;
+    f32x4 bb = *(const f32x4*)(g.bias + n);
+    f32x4 cs = {g.out_scale, g.out_scale, g.out_scale, g.out_scale};
+    if (g.colscale) {
+      const f32x4 q = *(const f32x4*)(g.colscale + n);
+      cs[0] *= q[0], cs[1] *= q[1], cs[2] *= q[2], cs[3] *= q[3];
+    }
+#pragma unroll
+    for (int i = 0; i < SG_RT; ++i) {
+      const int ml = i * 16 + frow;
+      f32x4 v = y[i][j];
+      v[0] = (v[0] + bb[0]) * cs[0], v[1] = (v[1] + bb[1]) * cs[1], v[2] = (v[2] + bb[2]) * cs[2], v[3] = (v[3] + bb[3]) * cs[3];
+      *(f32x4*)(stg + ml * D + (((n >> 2) ^ (ml & 31)) << 2)) = v;
+    }
+  }
+  sg_barrier();
+  const int cl = tid & 127, n = 4 * cl;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ml = (tid >> 7) + 4 * k;
+    const int64_t m = row0 + ml;
+    if (m >= g.M) continue;
+    f32x4 v = *(const f32x4*)(stg + ml * D + ((cl ^ (ml & 31)) << 2));
+    if (g.resid) {
+      const f32x4 q = *(const f32x4*)(g.resid + m * D + n);
+      v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
+    }
+    *(f32x4*)(g.out + m * D + n) = v;
+    if (g.out16) *(uint2*)(g.out16 + m * D + n) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
+  }
+}
+
+// stream[wave w][fragment f = 4 s + j][lane l][8]:  W[64 w + 16 j + (l & 15)][32 s + 8 (l >> 4) + e]   (N = 512, K = 512)
+template <typename HT>
+__global__ __launch_bounds__(256) void gemm_stream_pack_kernel(const float* w, uint16_t* out) {
+  for (int fi = blockIdx.x * 4 + (threadIdx.x >> 6); fi < 8 * 64; fi += gridDim.x * 4) {
+    const int l = threadIdx.x & 63, wv = fi >> 6, f = fi & 63, s = f >> 2, j = f & 3;
+    const float* src = w + (int64_t)(64 * wv + 16 * j + (l & 15)) * SG_D + 32 * s + 8 * (l >> 4);
+    uint4 o;
+    o.x = HT::pack(src[0], src[1]), o.y = HT::pack(src[2], src[3]), o.z = HT::pack(src[4], src[5]), o.w = HT::pack(src[6], src[7]);
+    *(uint4*)(out + (int64_t)fi * 512 + l * 8) = o;
+  }
+}
+
+}  // namespace
+
+int64_t gemm_stream_elems(int N, int K) { return (N == SG_D && K == SG_D) ? (int64_t)N * K + 8 * 512 : 0; }
+
+int gemm_stream_pack(const float* w, int N, int K, int h16, uint16_t* out, hipStream_t stream) {
+  if (!w || !out || N != SG_D || K != SG_D) return MDM_ERR_UNSUPPORTED;
+  if (hipMemsetAsync(out + (int64_t)N * K, 0, 8 * 512 * sizeof(uint16_t), stream) != hipSuccess) return MDM_ERR_LAUNCH;
+  if (h16 == MDM_H16_F16) {
+    hipLaunchKernelGGL(gemm_stream_pack_kernel<HF>, dim3(128), dim3(256), 0, stream, w, out);
+  } else {
+    hipLaunchKernelGGL(gemm_stream_pack_kernel<HB>, dim3(128), dim3(256), 0, stream, w, out);
+  }
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+bool style_gemm_supported(int D, int64_t M) { return D == SG_D && M > 0 && (M + SG_ROWS - 1) / SG_ROWS < (1ll << 30); }
+
+// src_fmt: 0 = fp32 source rows, else the launch's 16-bit format (must equal h16)
+int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
+               const float* sc, const int* pos4, const uint16_t* ws, const float* bias, const float* resid, float out_scale,
+               const float* colscale, float* out, uint16_t* out16, int h16, hipStream_t s) {
+  if (M <= 0) return MDM_OK;
+  if (!style_gemm_supported(D, M)) return MDM_ERR_UNSUPPORTED;
+  if (!src || !sw || !sb || !sc || !ws || !bias || !out || S <= 0 || (pw && !pb)) return MDM_ERR_ARG;
+  if ((h16 != MDM_H16_BF16 && h16 != MDM_H16_F16) || (src_fmt != 0 && src_fmt != h16) || ((uintptr_t)ws & 15)) return MDM_ERR_ARG;
+  StyleGemmArgs g = {src, M, S, pw, pb, sw, sb, sc, pos4, ws, bias, resid, out_scale, colscale, out, out16};
+  static DevOnce attr;
+  if (!attr) {
+    const void* fns[4] = {(const void*)style_gemm_kernel<HB, true>, (const void*)style_gemm_kernel<HB, false>,
+                          (const void*)style_gemm_kernel<HF, true>, (const void*)style_gemm_kernel<HF, false>};
+    for (const void* fn : fns)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SG_SMEM) != hipSuccess) return MDM_ERR_LAUNCH;
+    attr = true;
+  }
+  const dim3 grid((unsigned)((M + SG_ROWS - 1) / SG_ROWS));
+  if (h16 == MDM_H16_F16) {
+    if (src_fmt) hipLaunchKernelGGL((style_gemm_kernel<HF, true>), grid, dim3(SG_NT), SG_SMEM, s, g);
+    else hipLaunchKernelGGL((style_gemm_kernel<HF, false>), grid, dim3(SG_NT), SG_SMEM, s, g);
+  } else {
+    if (src_fmt) hipLaunchKernelGGL((style_gemm_kernel<HB, true>), grid, dim3(SG_NT), SG_SMEM, s, g);
+    else hipLaunchKernelGGL((style_gemm_kernel<HB, false>), grid, dim3(SG_NT), SG_SMEM, s, g);
+  }
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+}  // namespace mdm

@@ -181,6 +181,30 @@ class PackedModel:
                     dt = torch.float16 if fmt == "f16" else torch.bfloat16
                     self.wstream[k] = mlp_stream_pack(lay["W:" + k + "w1"].to(dev).reshape(E2, F_, D),
                                                       lay["W:" + k + "w2"].to(dev).reshape(E2, D, F_), dt)
+            # ... and of the dense Linear-GELU-Linear pairs (Performer output projection, 4x FFN of the text cross-attention),
+            # throughput modes only (their activations are 16-bit there); the mixed mode runs the FFN pair in fp16 as well
+            if os.environ.get("MDM_MLP_STREAM", "1") != "0" and D == 512 and precision in (L.PREC_BF16, L.PREC_F16, L.PREC_MIXED):
+                from .ops import mlp_stream_pack
+                for li in range(2 * L_):
+                    k = f"L{li}."
+                    pairs = [(k + "sd_ffn", k + "sd_f1", k + "sd_f2")]
+                    if precision != L.PREC_MIXED:
+                        pairs += [(k + w + ".proj", k + w + ".proj0", k + w + ".proj3") for w in ("local", "global")]
+                    for name, a, b in pairs:
+                        fmt = weight_format(a, precision, head_dim)
+                        if fmt not in ("f16", "bf16x2", "bf16"):
+                            continue
+                        dt = torch.float16 if fmt == "f16" else torch.bfloat16
+                        self.wstream[name] = mlp_stream_pack(lay["W:" + a].to(dev), lay["W:" + b].to(dev), dt)
+                    # out_layers.2 of the four StylizationBlocks, for the fused stylization kernel (csrc/style_gemm.hip)
+                    if precision != L.PREC_MIXED:
+                        from .ops import gemm_stream_pack
+                        for st in (k + "local.style.", k + "global.style.", k + "ca_style.", k + "ffn_style."):
+                            fmt = weight_format(st + "out", precision, head_dim)
+                            dt = torch.float16 if fmt == "f16" else torch.bfloat16
+                            ws = gemm_stream_pack(lay["W:" + st + "out"].to(dev), dt)
+                            if ws is not None:
+                                self.wstream[st + "out"] = ws
             self.layers = (L.Layer * (2 * L_))()
             for li, (pre, tag) in enumerate(layer_tags(L_)):
                 self._fill_layer(self.layers[li], f"L{li}.", pre, counters)
@@ -209,6 +233,8 @@ class PackedModel:
     def _style(self, st: L.Style, pre: str):
         st.norm_w, st.norm_b = self.V[pre + "norm_w"].data_ptr(), self.V[pre + "norm_b"].data_ptr()
         st.out, st.out_b = self._packed(pre + "out"), self.V[pre + "out_b"].data_ptr()
+        if (pre + "out") in self.wstream:
+            st.out_ws = self.wstream[pre + "out"].data_ptr()
 
     def _fill_layer(self, l: L.Layer, k: str, sd_prefix: str, counters):
         V, D = self.V, self.cfg["latent_dim"]
@@ -223,6 +249,8 @@ class PackedModel:
             p.feat = self._packed(q + "feat")
             p.proj0, p.proj0_b = self._packed(q + "proj0"), V[q + "proj0_b"].data_ptr()
             p.proj3, p.proj3_b = self._packed(q + "proj3"), V[q + "proj3_b"].data_ptr()
+            if (q + "proj") in self.wstream:
+                p.proj_ws = self.wstream[q + "proj"].data_ptr()
             self._style(p.style, q + "style.")
         l.skip, l.skip_b = self._packed(k + "skip"), V[k + "skip_b"].data_ptr()
         l.ca_norm_w, l.ca_norm_b = V[k + "ca_norm_w"].data_ptr(), V[k + "ca_norm_b"].data_ptr()
@@ -247,6 +275,8 @@ class PackedModel:
                 l.importance[b] = counters[br + ".expert_importance"].data_ptr()
         l.w1, l.b1 = self._packed(k + "w1"), V[k + "b1"].data_ptr()
         l.w2, l.b2 = self._packed(k + "w2"), V[k + "b2"].data_ptr()
+        if (k + "sd_ffn") in self.wstream:
+            l.sd_ffn_ws = self.wstream[k + "sd_ffn"].data_ptr()
         ws = self.wstream.get(k)
         if ws is not None:
             l.wstream, l.wstream_gs = ws.data_ptr(), 2 * D * self.cfg["ff_size"]
