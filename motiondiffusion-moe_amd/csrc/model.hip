@@ -467,7 +467,11 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
     // throughput mode: query GEMM + attention core + output GEMM + LayerNorm in one launch (csrc/sdfold.hip)
     MDM_TRY(sd_fold(x16, fold.kfold, fold.cb, fold.vfold, l.sd_out_b, l.sd_ln_w, l.sd_ln_b, c.B, c.S, D, H, N, w.t3,
                     (uint16_t*)w.t4, c.h16, c.s));
-    if (l.sd_ffn_ws && g_bf16_variant != 33) {  // the 4x FFN pair in one launch (knob 33: two GEMMs)
+    // the 4x FFN pair in one launch (knob 33: two GEMMs) at the full time scale only: at the half scale of the bench batch
+    // (6272 rows -> 32-row tiles, every workgroup streams the pair's 4 MB for 32 rows) it measures slower than the two GEMMs
+    // (78 vs 66 us; 100 vs 120 us at 12544 rows).  The choice is made on the FRAME count of the scale, never on the batch: a
+    // sample's result must not depend on the batch it travels in (shard invariance, cond | uncond batching)
+    if (l.sd_ffn_ws && g_bf16_variant != 33 && c.S >= 128) {
       MdmMlpDesc f = {};
       f.X = (const uint16_t*)w.t4, f.ldx = D, f.M = (int)c.M, f.Din = D, f.F = 4 * D, f.Dout = D;
       f.b1 = l.sd_f1_b, f.b2 = l.sd_f2_b, f.wstream = l.sd_ffn_ws, f.wstream_gs = 8 * (int64_t)D * D;

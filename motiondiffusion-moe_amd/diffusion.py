@@ -439,14 +439,15 @@ class _StepRunner:
     def _prepare(self):
         """Pack weights, build the text cache, size the workspace -- everything that allocates -- before capture.
         The warm-up forward must not disturb the MoE counters the reference would show (switch_moe.py:71-92)."""
-        saved = {k: v.clone() for k, v in self.model.moe_buffers().items()} if hasattr(self.model, "moe_buffers") else {}
-        self.xx.zero_()
-        self.t_dev.fill_(self.d.num_timesteps - 1)
-        self.noise.zero_()
-        self._step(self._needs_noise())
-        for k, v in saved.items():
-            self.model.moe_buffers()[k].copy_(v)
-        torch.cuda.current_stream().synchronize()
+        with torch.cuda.device(self.dev):  # the synchronize below must be on the sampler's device as well
+            saved = {k: v.clone() for k, v in self.model.moe_buffers().items()} if hasattr(self.model, "moe_buffers") else {}
+            self.xx.zero_()
+            self.t_dev.fill_(self.d.num_timesteps - 1)
+            self.noise.zero_()
+            self._step(self._needs_noise())
+            for k, v in saved.items():
+                self.model.moe_buffers()[k].copy_(v)
+            torch.cuda.current_stream().synchronize()
 
     def _philox_fill(self, out, stream_dev, stream_imm, s):
         """out[row] = noise(seed, global sample of that row, stream): rows are consecutive samples (first + row) or carry
@@ -483,6 +484,13 @@ class _StepRunner:
         """``seed``: draw x_T (when ``noise`` is None) and every step's noise (when ``step_noise`` is None) from the
         counter-based device generator keyed on (seed, sample_offset + row, timestep, element): the same global sample gets
         the same noise whatever the batch split.  Without a seed the torch generator is used, like the reference."""
+        # everything below -- the warm-up step, the graph capture, its replays, the noise draws -- runs with the SAMPLER'S device
+        # current: captured on another device's stream the graph would be empty and every replay a no-op (the reference's
+        # tools use torch.device('cuda:N') without set_device, tools/visualization.py:57)
+        with torch.cuda.device(self.dev):
+            return self._run(noise, step_noise, progress, callback, seed, sample_offset)
+
+    def _run(self, noise, step_noise, progress, callback, seed, sample_offset):
         d, B = self.d, self.B
         if seed is not None and step_noise is None:
             self.philox = (int(seed) & 0xFFFFFFFFFFFFFFFF, self._ids(sample_offset))

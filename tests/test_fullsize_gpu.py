@@ -128,14 +128,18 @@ def test_configs1_size_independent_properties():
 
 def test_configs0_end_to_end_against_the_oracle():
     """BASELINE configs[0]: small / 4 experts / B=2 / T=64 / 50-step DDPM with CFG, fp32-grade mode.  The oracle runs the
-    whole 50-step loop (100 forwards of B=2).  Every guided step of the HIP sampler is checked from the ORACLE's state
-    (teacher forcing) at <= 1e-3; the free-running loops are also compared: they agree to 1e-3 for the first steps and
-    then drift apart the way two fp32 implementations of a top-2 router do (one near-tie resolved differently is an O(1)
-    local change that the following steps amplify), so the free-running comparison is reported, not asserted."""
-    B, T, steps, scale = 2, 64, 50, 7.5
+    whole 50-step loop (100 forwards of B=2).  Every 7th guided step of the HIP sampler is checked from the ORACLE's state
+    (teacher forcing) and the routing of that step is dumped (mdm_route_dump) and compared with the oracle's: a step WITHOUT
+    a differing decision must match at <= 1e-3; a step with one is a near-tie resolved the other way by two fp32
+    implementations (an O(1) local change, not an error) and is accepted only if every differing decision sits at a token
+    whose oracle margin p2 - p3 is < 1e-5 and there are at most 2 of them per step.  The gate therefore does not depend on
+    how the compiler associates the gate logits' sums.  The free-running loops are compared for their first two steps."""
+    import ctypes as C
+    B, T, steps, scale, L = 2, 64, 50, 7.5, 4
     m, host, (x, length, xf_proj, xf_out) = _build(4, B, T, 3, seed=3)
     synth = pkg("synth")
     D = pkg("diffusion")
+    lib = pkg("_lib").lib()
     xo_u = synth.uniform_pm1((1, 28, 256), "in.uncond", 3) * (3.0 ** 0.5)
     xp_u = xo_u.mean(1)
     m.set_uncond_embedding(xp_u.cuda(), xo_u.cuda())
@@ -148,24 +152,51 @@ def test_configs0_end_to_end_against_the_oracle():
                                     step_noise=noises, callback=lambda i, t, xx: traj.__setitem__(i, xx.clone().cpu()))
     assert torch.isfinite(y).all()
     tb = DR.Tables(DR.linear_betas(steps))
+    names = [f"decoder_blocks_{s}.{i}.module" for s in ("low", "high") for i in range(L)]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
-    def model(xx, tt, cond):
+    def model(xx, tt, cond, trace):
         xp, xo = (xf_proj, xf_out) if cond else (xp_u.expand(B, -1), xo_u.expand(B, -1, -1))
-        return _oracle(host, xx, tt, length, xp, xo)
+        with torch.no_grad():
+            return R.denoiser_forward(host["sd"], host["mcfg"], xx, tt, length, xp, xo, host["eph"], host["proj"], None, trace)
 
     xs = x.clone()
-    forced_errs, free_errs = [], []
+    forced, free_errs = [], []
+    dump = torch.full((2 * L, 2, 2 * B * T, 2), -1, dtype=torch.int32, device="cuda")
     for i in range(steps):
         t = steps - 1 - i
         tt = torch.full((B,), t, dtype=torch.int64)
-        nxt, _ = DR.cfg_step(tb, t, xs, model(xs, tt, True), model(xs, tt, False), noises[i], scale)
-        if i % 7 == 0 or i == steps - 1:  # one HIP step from the oracle's state
-            out = diff.p_sample_with_cfg(m, xs.cuda(), tt.cuda(), clip_denoised=False, model_kwargs=kw, cfg_scale=scale,
-                                         noise=noises[i].cuda())
-            forced_errs.append((i, rel_inf(out["sample"].cpu(), nxt)))
+        tr_c, tr_u = {}, {}
+        nxt, _ = DR.cfg_step(tb, t, xs, model(xs, tt, True, tr_c), model(xs, tt, False, tr_u), noises[i], scale)
+        if i % 7 == 0 or i == steps - 1:  # one HIP step from the oracle's state, its routing dumped
+            lib.mdm_route_dump(C.c_void_p(dump.data_ptr()))
+            try:
+                out = diff.p_sample_with_cfg(m, xs.cuda(), tt.cuda(), clip_denoised=False, model_kwargs=kw, cfg_scale=scale,
+                                             noise=noises[i].cuda())
+                torch.cuda.synchronize()
+            finally:
+                lib.mdm_route_dump(C.c_void_p(0))
+            flips, worst_gap = 0, 0.0
+            for li, name in enumerate(names):
+                S = T // 2 if li < L else T
+                ours = dump[li].reshape(-1)[:4 * 2 * B * S].reshape(2, 2 * B * S, 2).cpu().long().sort(-1).values
+                for br in range(2):
+                    want = torch.cat([tr_c[f"{name}.ffn.branches.{br}.top2_idx"], tr_u[f"{name}.ffn.branches.{br}.top2_idx"]])
+                    gap = torch.cat([tr_c[f"{name}.ffn.branches.{br}.gap23"], tr_u[f"{name}.ffn.branches.{br}.gap23"]])
+                    diffm = (ours[br] != want.long().sort(-1).values).any(-1)
+                    flips += int(diffm.sum())
+                    if diffm.any():
+                        worst_gap = max(worst_gap, float(gap[diffm].max()))
+            forced.append((i, rel_inf(out["sample"].cpu(), nxt), flips, worst_gap))
         free_errs.append(rel_inf(traj[i], nxt))
         xs = nxt
-    print("teacher-forced step errors:", [(i, f"{e:.1e}") for i, e in forced_errs])
+    print("teacher-forced steps (step, rel err, routing decisions that differ, largest oracle p2-p3 among them):",
+          [(i, f"{e:.1e}", f, f"{gmax:.1e}") for i, e, f, gmax in forced])
     print("free-running loop divergence at steps 0, 1, 9, 24, 49:", [f"{free_errs[i]:.1e}" for i in (0, 1, 9, 24, 49)])
-    assert all(e < 1e-3 for _, e in forced_errs), forced_errs
+    for i, e, f, gmax in forced:
+        if f == 0:
+            assert e < 1e-3, (i, e)
+        else:
+            assert f <= 2 and gmax < 1e-5, (i, e, f, gmax)
+    assert sum(1 for _, _, f, _ in forced if f == 0) >= len(forced) - 2, forced
     assert free_errs[0] < 1e-3 and free_errs[1] < 1e-3

@@ -255,3 +255,70 @@ def test_training_losses_values_match_oracle():
     want = sum(T.MotionTransformer.load_balancing_loss(trace[k], trace[k.replace(".usage", ".importance")])
                for k in trace if k.endswith(".usage"))
     assert abs(float(terms["moe_loss"]) - float(want)) < 1e-3 * max(1.0, abs(float(want)))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_sampler_on_a_non_current_device_equals_the_current_device_run():
+    """with the model on cuda:1 while cuda:0 is the current device (what the reference's tools do with
+    torch.device('cuda:N') and no set_device), the warm-up, the graph capture and every replay must run on cuda:1
+    (sampler under `with torch.cuda.device(self.dev)`, per-device LDS-size attributes in the launchers)."""
+    g, meta, m0, diff, noises, kw = _setup()
+    d = diff(meta["steps_cfg"])
+    torch.cuda.set_device(0)
+    ns = noises("cfg", meta["steps_cfg"])
+    y0 = d.p_sample_loop_with_cfg(m0, tuple(g["x_T"].shape), noise=g["x_T"].cuda(), clip_denoised=False, model_kwargs=kw,
+                                  cfg_scale=meta["cfg_scale"], step_noise=ns, use_graph=True)
+    m1, _ = build_module(meta, device="cuda:1", precision=3)
+    m1.set_uncond_embedding(g["xf_proj_uncond"][:1].to("cuda:1"), g["xf_out_uncond"][:1].to("cuda:1"))
+    kw1 = {k: (v.to("cuda:1") if torch.is_tensor(v) else v) for k, v in kw.items()}
+    assert torch.cuda.current_device() == 0
+    y1 = d.p_sample_loop_with_cfg(m1, tuple(g["x_T"].shape), noise=g["x_T"].to("cuda:1"), clip_denoised=False, model_kwargs=kw1,
+                                  cfg_scale=meta["cfg_scale"], step_noise=ns, use_graph=True)
+    assert y1.device.index == 1 and torch.cuda.current_device() == 0
+    assert torch.equal(y0.cpu(), y1.cpu())
+
+
+def test_clipped_ddim_steps_match_the_oracle_away_from_the_clamp():
+    """ddim_sample_loop's default clip_denoised=True (gaussian_diffusion.py:523-528): pred_xstart = a x - b eps is clamped
+    to [-1, 1] and eps is re-derived from it with a gain of ~1e2 at high t, so ONE element whose unclamped value is within
+    the forward's error of +-1 is clamped by one implementation only -- that is why the free-running clipped loop above is
+    gated at 2e-2.  Here every step is taken from the ORACLE's state (teacher forcing): elements whose oracle pred_xstart
+    lies farther than `band` from +-1 must agree at 1e-3 in the step's sample, and the elements inside the band are counted
+    (a handful of the B*T*263, each allowed to land on either side of the clamp)."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import denoiser_ref as R
+    import diffusion_ref as DR
+    g, meta, m, diff, noises, kw = _setup()
+    steps = meta["steps_ddim"]
+    d = diff(steps)
+    kw2 = {k: kw[k] for k in ("xf_proj", "xf_out", "length")}
+    from conftest import golden_state
+    sd, eph, proj, mcfg = golden_state(meta)
+    tb = DR.Tables(DR.linear_betas(steps))
+    ns = noises("ddim.0.5", steps)
+    x = g["x_T"].clone()
+    B = x.shape[0]
+    band, in_band, checked = 2e-3, 0, 0
+    for i in range(steps):
+        t = steps - 1 - i
+        tt = torch.full((B,), t, dtype=torch.int64)
+        with torch.no_grad():
+            eps = R.denoiser_forward(sd, mcfg, x, tt, g["length"], g["xf_proj"], g["xf_out"], eph, proj)
+        nxt, x0c = DR.ddim_step(tb, t, x, eps, ns[i], 0.5, clip=True)
+        _, x0u = DR.ddim_step(tb, t, x, eps, ns[i], 0.5, clip=False)
+        if i % 4 == 0 or i == steps - 1:
+            out = d.ddim_sample(m, x.cuda(), tt.cuda(), clip_denoised=True, model_kwargs=kw2, eta=0.5, noise=ns[i].cuda())
+            near = (x0u.abs() - 1.0).abs() < band  # may be clamped by one side only
+            err = ((out["sample"].cpu() - nxt).abs() / nxt.abs().max())
+            in_band += int(near.sum())
+            checked += int((~near).sum())
+            assert float(err[~near].max()) < 1e-3, (i, float(err[~near].max()))
+            # pred_xstart itself carries the forward's eps error times b (~1e2 at high t): measured on the scale of the
+            # unclamped prediction, like every other comparison here
+            assert float((out["pred_xstart"].cpu() - x0c)[~near].abs().max() / x0u.abs().max()) < 1e-3, i
+        x = nxt
+    print(f"clipped DDIM, teacher-forced: {checked} elements away from the clamp agree at 1e-3; {in_band} within {band} of +-1")
+    assert in_band < 0.01 * (checked + in_band)
