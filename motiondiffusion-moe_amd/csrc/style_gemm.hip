@@ -21,9 +21,9 @@
 namespace mdm {
 namespace {
 
-constexpr int SG_NT = 512, SG_D = 512, SG_ROWS = 32, SG_RT = 2, SG_NJ = 4;
-constexpr int SG_IMG_B = SG_ROWS * SG_D * 2;       // 32 KiB
-constexpr int SG_SMEM = SG_ROWS * SG_D * 4;        // 64 KiB: the fp32 staging of the epilogue covers the image
+constexpr int SG_NT = 512, SG_D = 512, SG_NJ = 4;
+// RT row tiles (16 rows each) per workgroup: 2 -> 32 rows, <= 128 registers, two workgroups per CU; 4 -> 64 rows, one per CU (half
+// the weight bytes per row).  LDS: the fp32 staging of the epilogue (rows x 2 KiB) covers the 16-bit image (rows x 1 KiB).
 
 __device__ __forceinline__ void sg_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -48,8 +48,9 @@ struct StyleGemmArgs {
   uint16_t* out16;      // optional 16-bit copy
 };
 
-template <typename HT, bool SRC16>
-__global__ __launch_bounds__(SG_NT, 4) void style_gemm_kernel(const StyleGemmArgs g) {
+template <typename HT, bool SRC16, int SG_RT>
+__global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel(const StyleGemmArgs g) {
+  constexpr int SG_ROWS = 16 * SG_RT, RPW = SG_ROWS / 8;  // rows per wave in the row phase
   typedef typename HT::frag_t frag_t;
   typedef Row<8, true> R8;
   constexpr int D = SG_D, FMT = HT::FMT;
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(SG_NT, 4) void style_gemm_kernel(const StyleGemmArg
     if (g.pw) pww.load(g.pw, D, lane), pbb.load(g.pb, D, lane);
     sww.load(g.sw, D, lane), sbb.load(g.sb, D, lane);
 #pragma unroll 2
-    for (int q = 0; q < 4; ++q) {
-      const int rl = 4 * wn + q;
+    for (int q = 0; q < RPW; ++q) {
+      const int rl = RPW * wn + q;
       int64_t row = row0 + rl;
       row = row < g.M ? row : g.M - 1;  // rows past the end: recomputed copies of the last row, never stored
       const float* scb = g.sc + (row / g.S) * 2 * (int64_t)D;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(SG_NT, 4) void style_gemm_kernel(const StyleGemmArg
     }
   }
 
-  // ---- epilogue: (y + b) * out_scale * colscale staged as fp32 [32][512], full rows out with the residual -----------------
+  // ---- epilogue: (y + b) * out_scale * colscale staged as fp32 [rows][512], full rows out with the residual -----------------
   sg_barrier();
   float* stg = (float*)smem;
 #pragma unroll
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(SG_NT, 4) void style_gemm_kernel(const StyleGemmArg
   sg_barrier();
   const int cl = tid & 127, n = 4 * cl;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < SG_ROWS / 4; ++k) {
     const int ml = (tid >> 7) + 4 * k;
     const int64_t m = row0 + ml;
     if (m >= g.M) continue;
@@ -219,7 +220,32 @@ int gemm_stream_pack(const float* w, int N, int K, int h16, uint16_t* out, hipSt
   return MDM_OK;
 }
 
-bool style_gemm_supported(int D, int64_t M) { return D == SG_D && M > 0 && (M + SG_ROWS - 1) / SG_ROWS < (1ll << 30); }
+bool style_gemm_supported(int D, int64_t M) { return D == SG_D && M > 0 && M / 32 < (1ll << 30); }
+
+extern int g_bf16_variant;
+
+template <int RT>
+static int launch_style_gemm(const StyleGemmArgs& g, bool src16, int h16, hipStream_t s) {
+  constexpr int smem = 16 * RT * SG_D * 4;
+  static DevOnce attr;
+  if (!attr) {
+    const void* fns[4] = {(const void*)style_gemm_kernel<HB, true, RT>, (const void*)style_gemm_kernel<HB, false, RT>,
+                          (const void*)style_gemm_kernel<HF, true, RT>, (const void*)style_gemm_kernel<HF, false, RT>};
+    for (const void* fn : fns)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return MDM_ERR_LAUNCH;
+    attr = true;
+  }
+  const dim3 grid((unsigned)((g.M + 16 * RT - 1) / (16 * RT)));
+  if (h16 == MDM_H16_F16) {
+    if (src16) hipLaunchKernelGGL((style_gemm_kernel<HF, true, RT>), grid, dim3(SG_NT), smem, s, g);
+    else hipLaunchKernelGGL((style_gemm_kernel<HF, false, RT>), grid, dim3(SG_NT), smem, s, g);
+  } else {
+    if (src16) hipLaunchKernelGGL((style_gemm_kernel<HB, true, RT>), grid, dim3(SG_NT), smem, s, g);
+    else hipLaunchKernelGGL((style_gemm_kernel<HB, false, RT>), grid, dim3(SG_NT), smem, s, g);
+  }
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
 
 // src_fmt: 0 = fp32 source rows, else the launch's 16-bit format (must equal h16)
 int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
@@ -229,25 +255,11 @@ int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const floa
   if (!style_gemm_supported(D, M)) return MDM_ERR_UNSUPPORTED;
   if (!src || !sw || !sb || !sc || !ws || !bias || !out || S <= 0 || (pw && !pb)) return MDM_ERR_ARG;
   if ((h16 != MDM_H16_BF16 && h16 != MDM_H16_F16) || (src_fmt != 0 && src_fmt != h16) || ((uintptr_t)ws & 15)) return MDM_ERR_ARG;
-  StyleGemmArgs g = {src, M, S, pw, pb, sw, sb, sc, pos4, ws, bias, resid, out_scale, colscale, out, out16};
-  static DevOnce attr;
-  if (!attr) {
-    const void* fns[4] = {(const void*)style_gemm_kernel<HB, true>, (const void*)style_gemm_kernel<HB, false>,
-                          (const void*)style_gemm_kernel<HF, true>, (const void*)style_gemm_kernel<HF, false>};
-    for (const void* fn : fns)
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SG_SMEM) != hipSuccess) return MDM_ERR_LAUNCH;
-    attr = true;
-  }
-  const dim3 grid((unsigned)((M + SG_ROWS - 1) / SG_ROWS));
-  if (h16 == MDM_H16_F16) {
-    if (src_fmt) hipLaunchKernelGGL((style_gemm_kernel<HF, true>), grid, dim3(SG_NT), SG_SMEM, s, g);
-    else hipLaunchKernelGGL((style_gemm_kernel<HF, false>), grid, dim3(SG_NT), SG_SMEM, s, g);
-  } else {
-    if (src_fmt) hipLaunchKernelGGL((style_gemm_kernel<HB, true>), grid, dim3(SG_NT), SG_SMEM, s, g);
-    else hipLaunchKernelGGL((style_gemm_kernel<HB, false>), grid, dim3(SG_NT), SG_SMEM, s, g);
-  }
-  MDM_RETURN_IF_LAUNCH_FAILED();
-  return MDM_OK;
+  const StyleGemmArgs g = {src, M, S, pw, pb, sw, sb, sc, pos4, ws, bias, resid, out_scale, colscale, out, out16};
+  // knob 29: 64-row tiles (one workgroup per CU, half the weight bytes per row) -- measured 1 % of a step SLOWER than two
+  // co-resident 32-row workgroups per CU at 12544 rows; a row's arithmetic does not depend on the tile height
+  if (g_bf16_variant == 29) return launch_style_gemm<4>(g, src_fmt != 0, h16, s);
+  return launch_style_gemm<2>(g, src_fmt != 0, h16, s);
 }
 
 }  // namespace mdm
