@@ -127,7 +127,7 @@ typedef struct MdmMlpDesc {
   /* optional weight STREAM built by mdm_mlp_stream_pack from the same w1 / w2 (same 16-bit format): per (group, wave) one
    * linear run of 1-KiB MFMA fragments in consumption order (csrc/mlp_stream.hip).  When set and Dout == 512,
    * Din % 128 == 0, F % 256 == 0 the streamed-weight kernel runs and w1 / w2 are not read; wstream_gs = elements per
-   * group = F * Din + Dout * F.  The buffer must have mdm_mlp_stream_elems() elements (8 KiB of tail padding). */
+   * group = F * Din + Dout * F.  The buffer must have mdm_mlp_stream_elems() elements (16 KiB of tail padding). */
   const uint16_t* wstream;
   int64_t wstream_gs;
 } MdmMlpDesc;

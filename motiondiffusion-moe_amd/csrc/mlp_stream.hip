@@ -229,6 +229,7 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
   typedef XGeo<RT, DIN> G;
   constexpr int NKO = DIN / 128, NLINE = DIN / 64;
   constexpr int NA = 4, PD = NA - 1;  // A-fragment ring: NA registers, PD fragments ahead of the MFMAs
+  constexpr int NR = (RT == 4 && DIN % 256 == 0) ? 16 : 8;  // weight ring: fragments in flight per wave (16 where the accumulators leave room)
   constexpr int NF = 4 * RT;          // A fragments per unrolled body (4 K steps x RT row tiles)
   constexpr bool ILV = KO == 8;  // knob 48: GELU pieces interleaved with phase-2 MFMAs (measured 1.5 % SLOWER than back to back)
   static_assert(NF % NA == 0, "the ring must close over the unrolled body");
@@ -256,10 +257,10 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
     constexpr int fpc = (DIN / 32) * 2 + 8 * NJ;
     const uint8_t* wp = (const uint8_t*)g.wstream + ((int64_t)grp * g.wstream_gs + (int64_t)wn * nchunk * fpc * 512) * 2 + lane * 16;
 
-    frag_t R[8];
+    frag_t R[NR];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) R[f] = ldg<frag_t>(wp + f * 1024);
-    wp += 8192;  // wp + 1024 f is now the fragment that refills slot f
+    for (int f = 0; f < NR; ++f) R[f] = ldg<frag_t>(wp + f * 1024);
+    wp += NR * 1024;  // wp + 1024 f is now the fragment that refills slot f
 
     // ---- X tile -> LDS: wave w < RT brings rows 16 w .. 16 w + 15; one instruction = 8 rows x one 128-B line ---------------
     if (wn < RT) {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
         const int sq = k / RT, i = k % RT;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int slot = ((4 * HF + sq) * NJ + j) & 7;
+          const int slot = ((4 * HF + sq) * NJ + j) & (NR - 1);
           if constexpr (KO == 5) {
             asm volatile("" ::"v"(A[k % NA]), "v"(R[slot]));
           } else {
@@ -344,9 +345,9 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
         if (i == RT - 1) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const int slot = ((4 * HF + sq) * NJ + j) & 7;
+            const int slot = ((4 * HF + sq) * NJ + j) & (NR - 1);
             if constexpr (KO != 2) R[slot] = ldg<frag_t>(wp + slot * 1024);
-            if (slot == 7) wp += 8192;
+            if (slot == NR - 1) wp += NR * 1024;
           }
         }
         pin();
@@ -383,29 +384,35 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
       frag_t A[NA];
 #pragma unroll
       for (int k = 0; k < PD; ++k) A[k % NA] = *(const frag_t*)(ximg + (xb ^ (64 * (k / RT))) + (k % RT) * 16 * G::XROW_B);
+      constexpr int KB = NR / 8;  // unrolled bodies (4 K steps = 8 weight fragments each) per turn of the weight ring
+      static_assert(NKO % KB == 0, "the weight ring must close over phase 1");
 #pragma unroll 1
-      for (int ko = 0; ko < NKO; ++ko) {
-        const int kn = ko + 1 == NKO ? 0 : ko + 1;  // the body's last prefetches belong to the next body (the last ones are not used)
+      for (int ko = 0; ko < NKO; ko += KB) {
 #pragma unroll
-        for (int k = 0; k < NF; ++k) {
-          const int u = k / RT, i = k % RT;
-          if constexpr (KO == 4) {
-            asm volatile("" ::"v"(A[k % NA]), "v"(R[2 * u]), "v"(R[2 * u + 1]));
-          } else {
-            h[i][0] = HT::mfma16(R[2 * u], A[k % NA], h[i][0]);
-            h[i][1] = HT::mfma16(R[2 * u + 1], A[k % NA], h[i][1]);
-          }
-          const int kp = k + PD, up = (kp % NF) / RT, ip = kp % RT;
-          A[kp % NA] = *(const frag_t*)(ximg + (xb ^ (64 * up)) + (kp < NF ? ko : kn) * 256 + ip * 16 * G::XROW_B);
-          if (i == RT - 1) {
-            if constexpr (KO != 2) {
-              R[2 * u] = ldg<frag_t>(wp + (2 * u) * 1024);
-              R[2 * u + 1] = ldg<frag_t>(wp + (2 * u + 1) * 1024);
+        for (int kb = 0; kb < KB; ++kb) {
+          const int kc = ko + kb;
+          const int kn = kc + 1 == NKO ? 0 : kc + 1;  // the body's last prefetches belong to the next body (the last ones are not used)
+#pragma unroll
+          for (int k = 0; k < NF; ++k) {
+            const int u = k / RT, i = k % RT, s0 = 8 * kb + 2 * u;
+            if constexpr (KO == 4) {
+              asm volatile("" ::"v"(A[k % NA]), "v"(R[s0]), "v"(R[s0 + 1]));
+            } else {
+              h[i][0] = HT::mfma16(R[s0], A[k % NA], h[i][0]);
+              h[i][1] = HT::mfma16(R[s0 + 1], A[k % NA], h[i][1]);
             }
+            const int kp = k + PD, up = (kp % NF) / RT, ip = kp % RT;
+            A[kp % NA] = *(const frag_t*)(ximg + (xb ^ (64 * up)) + (kp < NF ? kc : kn) * 256 + ip * 16 * G::XROW_B);
+            if (i == RT - 1) {
+              if constexpr (KO != 2) {
+                R[s0] = ldg<frag_t>(wp + s0 * 1024);
+                R[s0 + 1] = ldg<frag_t>(wp + (s0 + 1) * 1024);
+              }
+            }
+            pin();
           }
-          pin();
         }
-        wp += 8192;
+        wp += NR * 1024;
       }
     };
     // publish pk[] as the half image: [image free] write [published]
@@ -559,14 +566,14 @@ int device_cus() {
 }  // namespace
 
 int64_t mlp_stream_elems(int G, int F, int Din, int Dout) {
-  // + 8 fragments: the ring's last refills of the last wave of the last group read (and discard) past the stream's end
-  return (int64_t)G * ((int64_t)F * Din + (int64_t)Dout * F) + 8 * 512;
+  // + 16 fragments: the ring's last refills of the last wave of the last group read (and discard) past the stream's end
+  return (int64_t)G * ((int64_t)F * Din + (int64_t)Dout * F) + 16 * 512;
 }
 
 int mlp_stream_pack(const float* w1, const float* w2, int G, int F, int Din, int Dout, int h16, uint16_t* out, hipStream_t stream) {
   if (!w1 || !w2 || !out || G < 1 || F < FC || (F % FC) || Din < 128 || (Din % 128) || (Dout != 512 && Dout != 1024)) return MDM_ERR_UNSUPPORTED;
   const int64_t body = (int64_t)G * ((int64_t)F * Din + (int64_t)Dout * F);
-  if (hipMemsetAsync(out + body, 0, 8 * 512 * sizeof(uint16_t), stream) != hipSuccess) return MDM_ERR_LAUNCH;
+  if (hipMemsetAsync(out + body, 0, 16 * 512 * sizeof(uint16_t), stream) != hipSuccess) return MDM_ERR_LAUNCH;
   const int blocks = (int)((body / 512 + 3) / 4 < 4096 ? (body / 512 + 3) / 4 : 4096);
   if (h16 == MDM_H16_F16) {
     hipLaunchKernelGGL(mlp_stream_pack_kernel<HF>, dim3(blocks), dim3(256), 0, stream, w1, w2, G, F, Din, Dout, out);

@@ -61,10 +61,10 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
 
   // the wave's weight stream: 64 fragments of 1 KiB; the ring's first 8 are requested before the row phase
   const uint8_t* wp = (const uint8_t*)g.ws + (int64_t)wn * 64 * 1024 + lane * 16;
-  frag_t R[8];
+  constexpr int NR = SG_RT <= 2 ? 16 : 8;  // ring depth: with 32 accumulator registers there is room for 16 fragments in flight
+  frag_t R[NR];  // the first 8 are requested before the row phase, the rest behind it (the row phase needs the registers)
 #pragma unroll
   for (int f = 0; f < 8; ++f) R[f] = *(const frag_t*)(wp + f * 1024);
-  wp += 8192;
 
   // ---- row phase (csrc/rowwise.hip style_in_rows, one wave per row) ------------------------------------------------------
   {
@@ -123,6 +123,9 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
       *(uint2*)(ir + (((32 + (lane >> 1)) ^ (rl & 15)) << 4)) = make_uint2(HT::pack(r.e[4], r.e[5]), HT::pack(r.e[6], r.e[7]));
     }
   }
+#pragma unroll
+  for (int f = 8; f < NR; ++f) R[f] = *(const frag_t*)(wp + f * 1024);
+  wp += NR * 1024;
   sg_barrier();
 
   // ---- GEMM phase: y[32 rows x 64 columns of this wave] = image . Wout^T ---------------------------------------------------
@@ -145,11 +148,11 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
       }
 #pragma unroll
       for (int j = 0; j < SG_NJ; ++j) {
-        const int slot = (s * SG_NJ + j) & 7;
+        const int slot = (s * SG_NJ + j) & (NR - 1);
 #pragma unroll
         for (int i = 0; i < SG_RT; ++i) y[i][j] = HT::mfma16(R[slot], A[s & 1][i], y[i][j]);
-        R[slot] = *(const frag_t*)(wp + slot * 1024);  // the last 8 refills read (and discard) the next wave's / the padding
-        if (slot == 7) wp += 8192;
+        R[slot] = *(const frag_t*)(wp + slot * 1024);  // the last NR refills read (and discard) the next wave's / the padding
+        if (slot == NR - 1) wp += NR * 1024;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -206,11 +209,11 @@ __global__ __launch_bounds__(256) void gemm_stream_pack_kernel(const float* w, u
 
 }  // namespace
 
-int64_t gemm_stream_elems(int N, int K) { return (N == SG_D && K == SG_D) ? (int64_t)N * K + 8 * 512 : 0; }
+int64_t gemm_stream_elems(int N, int K) { return (N == SG_D && K == SG_D) ? (int64_t)N * K + 16 * 512 : 0; }  // + the ring's overrun
 
 int gemm_stream_pack(const float* w, int N, int K, int h16, uint16_t* out, hipStream_t stream) {
   if (!w || !out || N != SG_D || K != SG_D) return MDM_ERR_UNSUPPORTED;
-  if (hipMemsetAsync(out + (int64_t)N * K, 0, 8 * 512 * sizeof(uint16_t), stream) != hipSuccess) return MDM_ERR_LAUNCH;
+  if (hipMemsetAsync(out + (int64_t)N * K, 0, 16 * 512 * sizeof(uint16_t), stream) != hipSuccess) return MDM_ERR_LAUNCH;
   if (h16 == MDM_H16_F16) {
     hipLaunchKernelGGL(gemm_stream_pack_kernel<HF>, dim3(128), dim3(256), 0, stream, w, out);
   } else {

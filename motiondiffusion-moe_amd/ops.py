@@ -163,7 +163,7 @@ def gemm_fp8(a8: torch.Tensor, a_scale: Optional[torch.Tensor], w: PackedWeight,
 def mlp_stream_pack(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Weight stream of the streamed-weight fused MLP (csrc/mlp_stream.hip, include/mdm_hip.h mdm_mlp_stream_pack):
     fp32 w1 (G, F, Din) / w2 (G, Dout, F) (or without the group axis) -> one 16-bit buffer holding, per (group, wave), the
-    1-KiB MFMA fragments of both layers in the order the wave consumes them (+ 8 KiB of tail padding)."""
+    1-KiB MFMA fragments of both layers in the order the wave consumes them (+ 16 KiB of tail padding)."""
     L.require_cuda(w1, w2)
     if w1.dim() == 2:
         w1, w2 = w1[None], w2[None]
@@ -221,7 +221,7 @@ def mlp_stream_pack_reference(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.d
         parts.append(b[:, :, c, 0])
     parts.append(b[:, :, Cn - 1, 1])
     s = torch.cat(parts, dim=2).to(dtype).reshape(-1)
-    return torch.cat([s, torch.zeros(8 * 512, dtype=dtype, device=s.device)])
+    return torch.cat([s, torch.zeros(16 * 512, dtype=dtype, device=s.device)])
 
 
 def fused_mlp(x16: torch.Tensor, w1: PackedWeight, b1: Optional[torch.Tensor], w2: PackedWeight,
