@@ -241,9 +241,11 @@ def mode_table(a, m_main, inputs, host, diff, kw, dev, main_prec, main_ms, steps
             m, _, _ = build_model(a.config, dev, prec, B, T, xf_out.shape[1], seed=0)
         dump = torch.full((L2, 2, B * T, 2), -1, dtype=torch.int32, device=dev)
         L.lib().mdm_route_dump(C.c_void_p(dump.data_ptr()))
-        outs[prec] = m(xd, t, ld, xf_proj=kw["xf_proj"], xf_out=kw["xf_out"]).clone()
-        torch.cuda.synchronize()
-        L.lib().mdm_route_dump(C.c_void_p(0))
+        try:  # the dump pointer is process-global in the library: never leave it pointing at a freed tensor
+            outs[prec] = m(xd, t, ld, xf_proj=kw["xf_proj"], xf_out=kw["xf_out"]).clone()
+            torch.cuda.synchronize()
+        finally:
+            L.lib().mdm_route_dump(C.c_void_p(0))
         routes[prec] = dump.sort(-1).values
         if prec == main_prec:
             ms = main_ms

@@ -27,7 +27,11 @@ __device__ __forceinline__ void glds16c(const void* g, uint8_t* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// e4m3fn has no infinity: a value beyond +-448 converts to NaN and would poison the row through the next GEMM, so the static-
+// scale outputs (the hidden layer at 8 x GELU) saturate first
 __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f), b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f), d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
   uint32_t r = 0;
   r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
   r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);

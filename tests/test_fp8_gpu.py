@@ -54,6 +54,25 @@ def test_dense_fp8_gemm(M, K, N):
     print(f"fp8 GEMM {M}x{K}x{N}: exact on quantised operands; vs the fp32 operands {rel_inf(y.cpu(), true.float().cpu()):.2e}")
 
 
+def test_fp8_hidden_output_saturates_instead_of_turning_nan():
+    """e4m3fn has no infinity, so a hidden activation above 448 / 8 = 56 would convert to NaN and poison the row
+    through the second GEMM.  The e4m3 output of the kernel saturates at +-448."""
+    L, ops = pkg("_lib"), pkg("ops")
+    M, K, N = 64, 128, 128
+    a = _rand(M, K, seed=5, scale=1.0)
+    a[3] *= 400.0   # a row of outliers: GELU(x) ~ x up to several hundred -> 8 x that is far beyond 448
+    w, b = _rand(N, K, seed=6, scale=1.0), _rand(N, seed=7, scale=0.1)
+    a8, asc = ops.quantize_rows_fp8(a)
+    pw = ops.PackedWeight(w, fmt="f8")
+    hid8 = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+    ops.gemm_fp8(a8, asc, pw, b, act=L.ACT_GELU, rows=M, out8=hid8, c8_scale=8.0)
+    h = hid8.view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(h).all() and float(h.abs().max()) == 448.0
+    ref = torch.nn.functional.gelu(_deq(a8, asc, K) @ _deq(pw.hi, pw.lo, K).T + b.double()) * 8.0
+    big = ref.abs() > 460
+    assert bool(big.any()) and torch.equal(h[big], torch.sign(ref[big]).float() * 448.0)
+
+
 def test_grouped_gathered_fp8_mlp_chain():
     """The expert MLP as the fp8 mode runs it: GEMM1 (gathered rows, grouped, GELU, e4m3 hidden with the static scale 8) then
     GEMM2 (uniform activation scale 1/8, gate-probability row scale), against fp64 on the same quantised tensors."""
