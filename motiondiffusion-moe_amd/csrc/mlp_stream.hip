@@ -191,14 +191,15 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     }                                              \
   } while (0)
 
-template <int RT, int DIN>
+template <int RT, int DIN, int NJ = 4>
 struct XGeo {
   static constexpr int ROWS = RT * 16;
   static constexpr int XROW_B = DIN * 2;     // X image: 16-B chunk c of row m at slot c ^ (m & 15)
   static constexpr int XIMG_B = ROWS * XROW_B;
   static constexpr int HID_B = ROWS * 256;   // half hidden chunk, 16-bit [ROWS][128]: chunk c of row m at slot c ^ (m & 15)
   static constexpr int IMG_B = XIMG_B + HID_B;
-  static constexpr int STG_B = ROWS * 1024 > 32768 ? ROWS * 1024 : 32768;  // epilogue staging: the 16-bit tile, or one fp32 row tile (Dout 512)
+  // epilogue staging: the whole 16-bit tile [ROWS][128 NJ], or at least one fp32 row tile [16][128 NJ]
+  static constexpr int STG_B = ROWS * NJ * 256 > NJ * 8192 ? ROWS * NJ * 256 : NJ * 8192;
   static constexpr int SMEM = IMG_B > STG_B ? IMG_B : STG_B;
 };
 
@@ -226,10 +227,10 @@ __device__ __forceinline__ f32x2 gelu_part_b(f32x2 v, f32x2 e) {
 template <typename HT, int RT, int NJ, int DIN, int KO>
 __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h) {
   typedef typename HT::frag_t frag_t;
-  typedef XGeo<RT, DIN> G;
+  typedef XGeo<RT, DIN, NJ> G;
   constexpr int NKO = DIN / 128, NLINE = DIN / 64;
   constexpr int NA = 4, PD = NA - 1;  // A-fragment ring: NA registers, PD fragments ahead of the MFMAs
-  constexpr int NR = (RT == 4 && DIN % 256 == 0) ? 16 : 8;  // weight ring: fragments in flight per wave (16 where the accumulators leave room)
+  constexpr int NR = (RT == 4 && NJ == 4 && DIN % 256 == 0) ? 16 : 8;  // weight ring: fragments in flight per wave (16 where the accumulators leave room)
   constexpr int NF = 4 * RT;          // A fragments per unrolled body (4 K steps x RT row tiles)
   constexpr bool ILV = KO == 8;  // knob 48: GELU pieces interleaved with phase-2 MFMAs (measured 1.5 % SLOWER than back to back)
   static_assert(NF % NA == 0, "the ring must close over the unrolled body");
@@ -585,7 +586,8 @@ int mlp_stream_pack(const float* w1, const float* w2, int G, int F, int Din, int
 }
 
 bool fused_mlp_stream_supported(const MdmMlpDesc& a) {
-  if (!a.wstream || a.Dout != 512 || (a.Din != 128 && a.Din != 256 && a.Din != 512) || a.F < FC || (a.F % FC) || a.M < 1) return false;
+  const bool small = a.Dout == 512 && (a.Din == 128 || a.Din == 256 || a.Din == 512), big = a.Dout == 1024 && a.Din == 1024;
+  if (!a.wstream || !(small || big) || a.F < FC || (a.F % FC) || a.M < 1) return false;
   if (a.goff && (a.ngroups < 1 || a.ngroups > 64)) return false;
   if ((a.ldx % 8) || ((((uintptr_t)a.X) | ((uintptr_t)a.wstream)) & 15) || (a.wstream_gs % 8)) return false;
   if ((a.ldc & 3) || (a.R1 && (a.ldr1 & 3)) || (a.R2 && (a.ldr2 & 3))) return false;
@@ -607,10 +609,9 @@ int mlp_stream_tile_h(int64_t M, int rt_max) {
 
 extern int g_bf16_variant;
 
-template <int RT, int DIN, int KO>
+template <int RT, int DIN, int KO, int NJ = 4>
 static int launch_stream(const MdmMlpDesc& a, int th, hipStream_t stream) {
-  constexpr int NJ = 4;
-  constexpr int smem = XGeo<RT, DIN>::SMEM;
+  constexpr int smem = XGeo<RT, DIN, NJ>::SMEM;
   static DevOnce attr;
   if (smem > 65536 && !attr) {
     if (hipFuncSetAttribute((const void*)fused_mlp_stream_kernel<HB, RT, NJ, DIN, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
@@ -644,6 +645,10 @@ static int launch_by_height(const MdmMlpDesc& a, hipStream_t stream) {
 int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream) {
   if (!a.X || (!a.C && !a.C16)) return MDM_ERR_ARG;
   if (!fused_mlp_stream_supported(a)) return MDM_ERR_UNSUPPORTED;
+  if (a.Dout == 1024) {  // big model (transformer.py:188-192 doubles the widths): 64-row tiles, 8 output fragments per wave and K step
+    const int th = mlp_stream_tile_h(a.M, 4);
+    return launch_stream<4, 1024, 0, 8>(a, th, stream);
+  }
   if (a.Din == 128) return launch_by_height<128>(a, stream);
   if (a.Din == 256) return launch_by_height<256>(a, stream);
   const int th = mlp_stream_tile_h(a.M, 7);

@@ -172,7 +172,7 @@ class PackedModel:
             self.wstream = {}
             E2, F_ = 2 * cfg["moe_num_experts"], cfg["ff_size"]
             import os
-            if (os.environ.get("MDM_MLP_STREAM", "1") != "0" and D == 512 and F_ % 256 == 0
+            if (os.environ.get("MDM_MLP_STREAM", "1") != "0" and D in (512, 1024) and F_ % 256 == 0
                     and precision in (L.PREC_BF16, L.PREC_F16, L.PREC_MIXED)):
                 from .ops import mlp_stream_pack
                 for li in range(2 * L_):

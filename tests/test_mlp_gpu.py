@@ -91,13 +91,14 @@ def test_weight_stream_packer_matches_the_documented_layout():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("sizes,F,Din", [([130, 0, 257, 1, 128], 1024, 512), ([3136] * 4, 1024, 512), ([64, 700], 256, 128),
-                                         ([113, 111, 112, 225, 17], 512, 256), ([300], 768, 512)])
+                                         ([113, 111, 112, 225, 17], 512, 256), ([300], 768, 512),
+                                         ([65, 0, 190, 1], 512, 1024), ([1600, 1500], 2048, 1024)])
 def test_streamed_weight_kernel(dtype, sizes, F, Din):
     """Streamed-weight fused expert MLP (csrc/mlp_stream.hip: weights global -> registers from the packed fragment stream,
     balanced tiles): grouped / gathered / ragged / empty groups, both 16-bit formats, fp32 and 16-bit outputs, against the
     fp64 reference with the same operand rounding, and against the LDS-staged kernel (knob 34) on the same inputs."""
     L, ops = pkg("_lib"), pkg("ops")
-    Dout, G, S = 512, len(sizes), 900
+    Dout, G, S = (1024 if Din == 1024 else 512), len(sizes), 900   # Din = 1024: the big model's widths (64-row tiles, Dout 1024)
     fmt = "f16" if dtype == torch.float16 else "bf16"
     M = sum(sizes)
     goff = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
@@ -126,7 +127,7 @@ def test_streamed_weight_kernel(dtype, sizes, F, Din):
     e32 = rel_inf(out[:M].cpu(), ref.float().cpu())
     e16 = rel_inf(out16[:M].float().cpu(), ref.float().cpu())
     d = None
-    if True:
+    if Dout == 512:  # the LDS-staged kernel has no Dout = 1024 form
         old = torch.empty((M, Dout), device="cuda")
         L.lib().mdm_set_gemm_variant(34)  # the LDS-staged kernel of csrc/mlp.hip
         try:
