@@ -281,11 +281,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   __syncthreads();
   MDM_STAMP(7);
   if (fast) {
+    // all staged rows out of LDS first (their reads need no row test): behind the per-row `continue` every read was its own block,
+    // `R w S | S |` sixteen times -- one exposed LDS latency per row
+    f32x4 vv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int ml = (tid >> 5) + 8 * k;
+      vv[k] = *(const f32x4*)(stg + ml * 128 + ((cl ^ (ml & 31)) << 2));
+    }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const int ml = (tid >> 5) + 8 * k, m = row0 + ml;
       if (m >= row_end) continue;
-      f32x4 v = *(const f32x4*)(stg + ml * 128 + ((cl ^ (ml & 31)) << 2));
+      f32x4 v = vv[k];
       v[0] += g.r1_scale * q1[k][0] + q2[k][0], v[1] += g.r1_scale * q1[k][1] + q2[k][1];
       v[2] += g.r1_scale * q1[k][2] + q2[k][2], v[3] += g.r1_scale * q1[k][3] + q2[k][3];
       if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;

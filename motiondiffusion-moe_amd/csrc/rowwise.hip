@@ -808,11 +808,11 @@ int style_in(const float* x, int64_t M, int D, int S, const float* pw, const flo
 
 // The router with compile-time expert count and hn format (D = 512 / 1024, E = 8 / 16, 16-bit hn rows): bit-identical to the
 // run-time version (tests/test_blocks_gpu.py) and 2 % of a step faster at both model sizes (5.85 -> 5.74 and 15.59 -> 15.27 ms,
-// alternating runs on one box).  Default for D = 512, E = 8 (the combination the bit-equality test covers); knob 26 takes it
-// wherever it exists, knob 27 never.
+// alternating runs on one box).  Default for E = 8 at D = 512 and D = 1024 (the combinations the bit-equality tests cover:
+// tests/test_blocks_gpu.py, tests/test_bigsize_gpu.py); knob 26 takes it wherever it exists, knob 27 never.
 bool gate16_const_wanted(int nv, int E) {
   if (g_bf16_variant == 27) return false;
-  return g_bf16_variant == 26 || (nv == 8 && E == 8);
+  return g_bf16_variant == 26 || ((nv == 8 || nv == 16) && E == 8);
 }
 template <int NV, int EX, int HNF>
 bool launch_gate16_const(int grid, int smem, hipStream_t s, const float* x, int64_t M, int D, int E, const MoeGateParams& p) {

@@ -291,3 +291,24 @@ def test_big_width_linear_cross_attention_fused_core(S, N, precision, tol):
     # in the bf16 mode the GEMM-composed path rounds the same operands to bf16 and accumulates in the same MFMA order: the two
     # paths may agree bit for bit; in the fp16 mode the composed path still rounds to bf16 and must differ
     assert precision == 1 or not torch.equal(fused, chain)
+    assert precision == 1 or not torch.equal(fused, chain)
+
+
+@pytest.mark.parametrize("precision", [2, 1])
+def test_big_width_router_with_compile_time_expert_count_is_bit_identical(precision):
+    """D = 1024, E = 8: the router instantiated for the expert count and hn format (knob 26) against the run-time one
+    (knob 27) through a whole forward at a ragged batch -- same arithmetic in the same order, so bit-equal outputs."""
+    B, T = 3, 37
+    m, host = _big(precision)
+    x, length, xf_proj, xf_out = _inputs(B, T)
+    t = torch.full((B,), 500, dtype=torch.int64)
+    lib = pkg("_lib").lib()
+    outs = {}
+    for knob in (27, 26):
+        lib.mdm_set_gemm_variant(knob)
+        try:
+            outs[knob] = m(x.cuda(), t.cuda(), length.cuda(), xf_proj=xf_proj.cuda(), xf_out=xf_out.cuda()).cpu()
+        finally:
+            lib.mdm_set_gemm_variant(0)
+    assert torch.isfinite(outs[26]).all()
+    assert torch.equal(outs[26], outs[27]), float((outs[26] - outs[27]).abs().max())
