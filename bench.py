@@ -543,7 +543,7 @@ def main():
         }
         if dom is not None:
             line["roofline"]["dominant_kernel_alone"] = {
-                "name": "fused_mlp_xres_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip)", "achieved": round(dom[1] / dom[0] / 1e12, 2),
+                "name": "fused_mlp_stream_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip)", "achieved": round(dom[1] / dom[0] / 1e12, 2),
                 "us": round(dom[0] * 1e6, 1), "frac": round(dom[1] / dom[0] / PEAK[a.precision], 4),
                 "flop_per_launch": dom[1], "timed_with": "HIP events on the launch stream, kernel alone, balanced routing"}
         if live is not None:
@@ -559,10 +559,10 @@ def main():
                        "traffic": pmc_k,
                        "traffic_note": "fabric bytes per launch of this kernel (mean over its launches in a step), rocprofv3 "
                                        "--pmc FETCH_SIZE(x2) / WRITE_SIZE passes, profiles/r03_pmc_traffic.json" if pmc_k else None,
-                       "what": "dominant kernel fused_mlp_xres_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip): mean algorithmic FLOP per "
+                       "what": "dominant kernel fused_mlp_stream_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip): mean algorithmic FLOP per "
                                "launch (4 * routed rows * D * F) / mean launch duration over the launches of real sampling "
                                "steps; the whole step is under whole_step",
-                       "kernel": "fused_mlp_xres_kernel", "launch_us_mean": round(live[0] * 1e6, 1),
+                       "kernel": "fused_mlp_stream_kernel", "launch_us_mean": round(live[0] * 1e6, 1),
                        "flop_per_launch_mean": live[1], "launches_timed": len(live[2]),
                        "launches": [{"rows": rw, "us": round(u, 1)} for rw, u in live[2][:8]],
                        "timed_with": "HIP events recorded by the library on the launch stream around every launch of the "
