@@ -98,7 +98,8 @@ int mdm_gemm(const MdmGemmDesc* desc, void* stream);
  * the hidden activations stay on chip.  Replaces the Linear-GELU-Linear pairs of the path: the expert MLPs
  * (switch_moe.py:19-25, grouped by goff with per-expert strides w?_gs / b?_gs), the 4x FFN of the text cross-attention
  * block (fast_attention.py:293-299) and the Performer output projection (fast_attention.py:121-126).
- * Supported shapes: Dout == 512, Din % 64 == 0, F % 256 == 0; anything else returns MDM_ERR_UNSUPPORTED. */
+ * Supported shapes: Dout == 512, Din % 64 == 0, F % 256 == 0 (LDS-staged kernel); with a weight stream (below) Dout == 512 and
+ * Din in {128, 256, 512}, or Dout == Din == 1024; anything else returns MDM_ERR_UNSUPPORTED. */
 typedef struct MdmMlpDesc {
   const uint16_t* X; /* bf16 rows [*, Din] */
   int64_t ldx;
@@ -125,9 +126,9 @@ typedef struct MdmMlpDesc {
   int64_t ldc;
   int32_t h16;   /* MDM_H16_*: format of X, w1, w2 and C16 (0 = bf16) */
   /* optional weight STREAM built by mdm_mlp_stream_pack from the same w1 / w2 (same 16-bit format): per (group, wave) one
-   * linear run of 1-KiB MFMA fragments in consumption order (csrc/mlp_stream.hip).  When set and Dout == 512,
-   * Din % 128 == 0, F % 256 == 0 the streamed-weight kernel runs and w1 / w2 are not read; wstream_gs = elements per
-   * group = F * Din + Dout * F.  The buffer must have mdm_mlp_stream_elems() elements (16 KiB of tail padding). */
+   * linear run of 1-KiB MFMA fragments in consumption order (csrc/mlp_stream.hip).  When set and the shape is one of the
+   * streamed kernel's (above; F % 256 == 0, ngroups <= 64) that kernel runs and w1 / w2 are not read; wstream_gs = elements
+   * per group = F * Din + Dout * F.  The buffer must have mdm_mlp_stream_elems() elements (16 KiB of tail padding). */
   const uint16_t* wstream;
   int64_t wstream_gs;
 } MdmMlpDesc;
@@ -231,6 +232,12 @@ typedef struct MdmTextCache {
   uint16_t* sd_kfold; /* 16-bit [2L, B, P, 128, D]  K'[hs*N + n, :] = key_h[n, :] Wq_h / sqrt(dh); P = mdm_sd_fold_passes, hs = h mod heads-per-pass */
   float* sd_cb;       /* fp32   [2L, B, P, 128]     key_h[n, :] . bq_h / sqrt(dh) */
   uint16_t* sd_vfold; /* 16-bit [2L, B, P, D, 128]  V'^T[:, hs*N + n] = Wout[:, h] value_h[n, :]^T */
+  /* optional int32 [B] on the device, 1 <= ntok[b] <= N: sample b's own text token count; rows ntok[b] .. N-1 of its xf_out
+   * are padding that neither cross-attention sees (weight exactly 0 in both softmaxes).  NULL = every sample has N tokens.
+   * The reference has no text mask (fast_attention.py:249,317-320): this exists so that forwards the reference runs
+   * separately because their captions tokenise to different lengths -- the cond and uncond halves of a guided step,
+   * gaussian_diffusion.py:1060-1073 -- can travel as rows of one batch and still see exactly their own tokens. */
+  const int32_t* ntok;
 } MdmTextCache;
 
 /* Optional per-loop stem cache: the time-embedding chain (time.py:15-31 -> time_embed -> time_proj -> gated_fusion.proj_time,
@@ -397,11 +404,13 @@ int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
 
 /* Kernel-selection knob for same-box A/B runs and tests (0 = default; process-global, not thread-safe, never part of the data
  * path).  Values: 1 / 2 force the 128- / 64-row tile of the 16-bit GEMM, 6 / 7 force / forbid its 256 x 256 tile, 28 two-stage
- * ring in the 64-row tile; 21 expert MLP as two GEMMs instead of the fused kernel, 35 its second-generation kernel (41-44 that
- * kernel's timing-only knock-outs); 22 unfolded text cross-attention, 24 folded at any pass count; 23 generic head_dim-256 paths;
- * 25 fp32 instead of 16-bit intermediates; 26 / 27 router with compile-time / run-time expert count wherever both exist; 31
- * input embedding in the mode's own precision; 36 fp32-grade Linears on the register-staged kernel, 37-39 ring depths of the
- * LDS-DMA fp32-grade kernel. */
+ * ring in the 64-row tile; 21 expert MLP as two GEMMs instead of the fused kernel, 34 the LDS-staged fused kernel (csrc/mlp.hip)
+ * instead of the streamed-weight one (csrc/mlp_stream.hip; 41-49 that kernel's timing-only knock-outs and its stamped build:
+ * results are wrong under them); 32 / 33 the Performer proj_out pair / the 4x FFN pair as two GEMMs; 30 stylization input and
+ * its Linear as two launches, 29 that kernel on 64-row tiles; 22 unfolded text cross-attention, 24 folded at any pass count;
+ * 23 generic head_dim-256 paths; 25 fp32 instead of 16-bit intermediates; 26 / 27 router with compile-time / run-time expert
+ * count wherever both exist; 31 input embedding in the mode's own precision; 36 fp32-grade Linears on the register-staged
+ * kernel, 37-39 ring depths of the LDS-DMA fp32-grade kernel. */
 int mdm_set_gemm_variant(int variant);
 /* diagnostic: s_memtime stamps of block 0 of the last bf16 GEMM launched with feat_S == -77 (host copy, synchronises) */
 int mdm_debug_stamps(uint64_t* out16);

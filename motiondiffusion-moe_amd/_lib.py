@@ -109,7 +109,8 @@ class Model(C.Structure):
 
 class TextCache(C.Structure):
     _fields_ = [("lin_at", C.c_void_p), ("sd_k", C.c_void_p), ("sd_v", C.c_void_p), ("B", C.c_int32),
-                ("N", C.c_int32), ("sd_kfold", C.c_void_p), ("sd_cb", C.c_void_p), ("sd_vfold", C.c_void_p)]
+                ("N", C.c_int32), ("sd_kfold", C.c_void_p), ("sd_cb", C.c_void_p), ("sd_vfold", C.c_void_p),
+                ("ntok", C.c_void_p)]
 
 
 class StemCache(C.Structure):

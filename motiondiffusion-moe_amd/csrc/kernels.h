@@ -49,12 +49,13 @@ bool perf_attn256_supported(int dh, int S);
 int64_t perf_attn256_scratch_bytes(int B, int H, int S);
 int perf_attn256(const void* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len,
                  int B, int S, int H, uint16_t* out, void* scratch, hipStream_t s);
-int row_softmax(float* sc, int64_t rows, int N, hipStream_t s);
+// ntok (optional, int32 [rows / rows_per_b]): row r attends to its first ntok[r / rows_per_b] columns only, the rest get 0
+int row_softmax(float* sc, int64_t rows, int N, hipStream_t s, const int32_t* ntok = nullptr, int64_t rows_per_b = 1);
 // fused text cross-attention cores (xattn.hip), head_dim 128
 bool xattn_supported(int dh, int N);
 bool lin_xattn_supported(int dh);  // linear cross-attention core: head_dim 128 or 256
 int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
-            float* out32, int h16, hipStream_t s);
+            float* out32, int h16, hipStream_t s, const int32_t* ntok = nullptr);  // ntok: per-sample token counts [B] or null
 int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
               int h16, hipStream_t s);
 // sdfold.hip: text cross-attention with folded projections + the following LayerNorm, one launch
@@ -64,7 +65,9 @@ int sd_fold_passes(int H, int N);
 int sd_fold(const uint16_t* x16, const uint16_t* kfold, const float* cb, const uint16_t* vfold, const float* bout,
             const float* ln_w, const float* ln_b, int B, int S, int D, int H, int N, float* out32, uint16_t* out16,
             int h16, hipStream_t s);
-int col_softmax(float* k, int B, int N, int D, hipStream_t s);
+int col_softmax(float* k, int B, int N, int D, hipStream_t s, const int32_t* ntok = nullptr);  // ntok: tokens >= ntok[b] get 0
+// cb [B][np][128] += -1e30 on the folded columns hs * N + n with n >= ntok[b] (csrc/sdfold.hip: per-row text token counts)
+int sd_fold_mask_cb(float* cb, int B, int np, int hpp, int N, const int32_t* ntok, hipStream_t s);
 int sinusoid(const int64_t* t, int B, int D, float* out, hipStream_t s);
 int gated_mix(const float* t, const float* x, int64_t n, float* out, hipStream_t s);
 int gated_mix_gather(const float* table, const int64_t* ts, int steps, const float* x, int B, int D, float* out,

@@ -96,6 +96,7 @@ struct Ctx {
   bool mix;         // precision 4: fp32-grade flow, but expert MLPs + the 4x FFN run as ONE fp16 pass on 16-bit operands
   bool fp8;         // precision 5: as 2, expert GEMMs on e4m3 operands (csrc/gemm8.hip)
   int B, S, N;      // batch, frames at this scale, text tokens
+  const int32_t* ntok = nullptr;  // per-sample text token counts [B] (MdmTextCache.ntok), or null: all N
   int64_t M;        // B*S
   const int* len;   // lengths at this scale
   Work w;
@@ -494,7 +495,7 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
                    fz ? (uint16_t*)w.t1 : nullptr, o));
   }
   if (c.bf && xattn_supported(dh, N) && !(dh == 256 && g_bf16_variant == 23)) {
-    MDM_TRY(sd_attn(w.t1, c.h16, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.h16, c.s));  // scores, softmax, PV fused
+    MDM_TRY(sd_attn(w.t1, c.h16, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.h16, c.s, c.ntok));  // scores, softmax, PV fused
   } else {
     {
       GemmArgs g = gd(c);  // scores[b,h,s,n] = q . k
@@ -507,7 +508,7 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
       g.C = w.scr, g.ldc = N, g.c_bs1 = (int64_t)H * c.S * N, g.c_bs2 = (int64_t)c.S * N;
       MDM_TRY(gemm(g, c.s));
     }
-    MDM_TRY(row_softmax(w.scr, c.M * H, N, c.s));
+    MDM_TRY(row_softmax(w.scr, c.M * H, N, c.s, c.ntok, (int64_t)H * c.S));
     {
       GemmArgs g = gd(c);  // o[b,s,h,:] = p v
       g.A = op_f32(w.scr, N);
@@ -681,6 +682,7 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
   // computed once per caption batch, never per step: always the bf16x3 arithmetic (its weights are packed bf16 hi + lo in
   // every mode); `precision` only selects the 16-bit format of the folded K' / V' images
   c.m = m, c.s = (hipStream_t)stream, c.prec = 3, c.bf = false, c.mix = false, c.B = tc->B, c.N = tc->N;
+  c.ntok = tc->ntok;
   c.h16 = (precision == MDM_PREC_F16 || precision == MDM_PREC_MIXED || precision == MDM_PREC_FP8) ? MDM_H16_F16 : MDM_H16_BF16;
   c.w = carve(*m, tc->B, 2, tc->N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
@@ -690,7 +692,7 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
     const MdmLayer& l = m->layers[layer];
     MDM_TRY(ln_chain(xf_out, BN, m->Dt, l.ca_tnorm_w, l.ca_tnorm_b, c.w.tn, 0, nullptr, nullptr, nullptr, 0, c.s));
     MDM_TRY(linear(c, act_f32(c.w.tn), BN, m->Dt, l.ca_k, l.ca_k_b, D, c.w.kb, nullptr));
-    MDM_TRY(col_softmax(c.w.kb, B, N, D, c.s));  // softmax over text tokens (fast_attention.py:249)
+    MDM_TRY(col_softmax(c.w.kb, B, N, D, c.s, tc->ntok));  // softmax over text tokens (fast_attention.py:249)
     MDM_TRY(linear(c, act_f32(c.w.tn), BN, m->Dt, l.ca_v, l.ca_v_b, D, c.w.vb, nullptr));
     GemmArgs g = gemm_defaults(3);  // A^T[b,h][l][d] = sum_n v[n,l] k[n,d]   (fast_attention.py:252)
     g.A = op_f32_kstride(c.w.vb, D);
@@ -751,6 +753,8 @@ int mdm_text_cache_build(const MdmModel* m, const float* xf_out, const MdmTextCa
           MDM_TRY(gemm(g, c.s));
         }
       }
+      // per-sample token counts: the folded columns of a sample's padding tokens get a bias that makes their probability 0
+      MDM_TRY(sd_fold_mask_cb((float*)f.cb, B, np, hpp, N, tc->ntok, c.s));
     }
   }
   return MDM_OK;
@@ -804,6 +808,7 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
   if (tc->B != B) return MDM_ERR_ARG;
   Ctx c = {};
   c.m = m, c.s = (hipStream_t)stream, c.B = B, c.N = tc->N;
+  c.ntok = tc->ntok;
   if (!set_precision(c, m, precision)) return MDM_ERR_UNSUPPORTED;
   c.w = carve(*m, B, T, tc->N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
@@ -863,6 +868,7 @@ int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const Mdm
   c.m = m, c.s = (hipStream_t)stream, c.B = B, c.S = S, c.M = (int64_t)B * S, c.len = len;
   if (!set_precision(c, m, precision)) return MDM_ERR_UNSUPPORTED;
   c.N = tc ? tc->N : 1;
+  c.ntok = tc ? tc->ntok : nullptr;
   c.w = carve(*m, B, S, c.N, ws);
   if (c.w.bytes > ws_bytes) return MDM_ERR_ARG;
   const MdmLayer& l = m->layers[layer];

@@ -588,24 +588,26 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(float* __restrict__ q
   } while (0)
 
 // softmax over the last dim N <= 128 of a (rows, N) matrix, 32 lanes per row, in place (fast_attention.py:320)
-__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ s, int64_t rows, int N) {
+__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ s, int64_t rows, int N, const int32_t* __restrict__ ntok,
+                                                          int64_t rows_per_b) {
   const int gl = threadIdx.x & 31;
   const int64_t gid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 5;
   const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 5;
   for (int64_t r = gid; r < rows; r += ng) {
     float* p = s + r * N;
+    const int nv = ntok ? min(max(ntok[r / rows_per_b], 1), N) : N;  // this row's sample attends to its first nv text tokens
     float v[4], mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = gl + 32 * j;
-      v[j] = i < N ? p[i] : -INFINITY;
+      v[j] = i < nv ? p[i] : -INFINITY;
       mx = fmaxf(mx, v[j]);
     }
     mx = group_max<32>(mx);
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      v[j] = (gl + 32 * j < N) ? expf(v[j] - mx) : 0.f;
+      v[j] = (gl + 32 * j < nv) ? expf(v[j] - mx) : 0.f;
       sum += v[j];
     }
     sum = group_sum<32>(sum);
@@ -616,16 +618,26 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ s,
 }
 
 // softmax over the token axis n of k (B,N,D), one thread per (b, column), in place (fast_attention.py:249)
-__global__ void col_softmax_kernel(float* __restrict__ k, int B, int N, int D) {
+__global__ void col_softmax_kernel(float* __restrict__ k, int B, int N, int D, const int32_t* __restrict__ ntok) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * D) return;
   const int64_t b = i / D, c = i - b * D;
   float* p = k + b * N * (int64_t)D + c;
+  const int nv = ntok ? min(max(ntok[b], 1), N) : N;  // tokens past the sample's own count are padding: weight 0
   float mx = -INFINITY;
-  for (int n = 0; n < N; ++n) mx = fmaxf(mx, p[(int64_t)n * D]);
+  for (int n = 0; n < nv; ++n) mx = fmaxf(mx, p[(int64_t)n * D]);
   float s = 0.f;
-  for (int n = 0; n < N; ++n) s += expf(p[(int64_t)n * D] - mx);
-  for (int n = 0; n < N; ++n) p[(int64_t)n * D] = expf(p[(int64_t)n * D] - mx) / s;
+  for (int n = 0; n < nv; ++n) s += expf(p[(int64_t)n * D] - mx);
+  for (int n = 0; n < nv; ++n) p[(int64_t)n * D] = expf(p[(int64_t)n * D] - mx) / s;
+  for (int n = nv; n < N; ++n) p[(int64_t)n * D] = 0.f;
+}
+
+// folded text cross-attention: bias -1e30 on the columns of padded tokens, so that their probability is exactly 0
+__global__ void sd_fold_mask_cb_kernel(float* __restrict__ cb, int B, int np, int hpp, int N, const int32_t* __restrict__ ntok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * np * 128) return;
+  const int b = i / (np * 128), col = i & 127;
+  if (col < hpp * N && col % N >= min(max(ntok[b], 1), N)) cb[i] = -1e30f;
 }
 
 // ---- stem pieces ---------------------------------------------------------------------------------
@@ -923,18 +935,27 @@ int head_softmax(float* q, int64_t units, int dh, hipStream_t s) {
   return MDM_OK;
 }
 
-int row_softmax(float* sc, int64_t rows, int N, hipStream_t s) {
+int row_softmax(float* sc, int64_t rows, int N, hipStream_t s, const int32_t* ntok, int64_t rows_per_b) {
   if (rows <= 0) return MDM_OK;
-  if (N < 1 || N > 128) return MDM_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(row_softmax_kernel, dim3(unit_grid(rows, 32)), dim3(256), 0, s, sc, rows, N);
+  if (N < 1 || N > 128 || rows_per_b < 1) return MDM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(row_softmax_kernel, dim3(unit_grid(rows, 32)), dim3(256), 0, s, sc, rows, N, ntok, rows_per_b);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
 
-int col_softmax(float* k, int B, int N, int D, hipStream_t s) {
+int col_softmax(float* k, int B, int N, int D, hipStream_t s, const int32_t* ntok) {
   const int64_t n = (int64_t)B * D;
   if (n <= 0) return MDM_OK;
-  hipLaunchKernelGGL(col_softmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, B, N, D);
+  hipLaunchKernelGGL(col_softmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, B, N, D, ntok);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+int sd_fold_mask_cb(float* cb, int B, int np, int hpp, int N, const int32_t* ntok, hipStream_t s) {
+  const int n = B * np * 128;
+  if (n <= 0 || !ntok) return MDM_OK;
+  if (!cb || N < 1) return MDM_ERR_ARG;
+  hipLaunchKernelGGL(sd_fold_mask_cb_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cb, B, np, hpp, N, ntok);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }

@@ -57,7 +57,8 @@ __device__ __forceinline__ void load_row(const void* __restrict__ base, int64_t 
 template <typename HT, int NT32, bool IN16, int DHT>  // ceil(N / 32); q stored as 16-bit or fp32; head_dim 128 or 256
 __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ qm, const float* __restrict__ kc,
                                                       const float* __restrict__ vc, int S, int H, int N,
-                                                      uint16_t* __restrict__ out16, float* __restrict__ out32) {
+                                                      uint16_t* __restrict__ out16, float* __restrict__ out32,
+                                                      const int32_t* __restrict__ ntok) {
   typedef typename HT::frag_t frag_t;
   constexpr int DH = DHT, PS = DHT + 8;  // (shadow the file-level head_dim-128 constants)
   extern __shared__ __attribute__((aligned(16))) uint16_t sd_smem[];
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
   uint16_t* vT = sd_smem + NT32 * 32 * PS;  // v^T [d][n], DH rows of NS
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
+  const int nv = ntok ? min(max(ntok[b], 1), N) : N;  // this sample's own text tokens (the rest of its N rows is padding)
   for (int i = tid; i < NT32 * 32 * (DH / 4); i += XNT) {
     const int n = i / (DH / 4), c = i - n * (DH / 4);
     f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(XNT) void sd_attn_kernel(const void* __restrict__ q
     for (int nt = 0; nt < 2 * NT32; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (16 * nt + 4 * q + r >= N) sc[nt][r] = -INFINITY;
+        if (16 * nt + 4 * q + r >= nv) sc[nt][r] = -INFINITY;
         mx = fmaxf(mx, sc[nt][r]);
       }
     mx = quad_max(mx);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(XNT, 2) void lin_xattn256_kernel(const void* __rest
 
 template <typename HT, int NT32, bool IN16, int DHT>
 int launch_sd(const void* q, const float* kc, const float* vc, int B, int S, int H, int N, uint16_t* out16, float* out32,
-              hipStream_t s) {
+              hipStream_t s, const int32_t* ntok) {
   constexpr int smem = (NT32 * 32 * (DHT + 8) + DHT * NS) * 2;
   static DevOnce attr;
   if (smem > 65536 && !attr) {
@@ -294,7 +296,7 @@ int launch_sd(const void* q, const float* kc, const float* vc, int B, int S, int
       return MDM_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((sd_attn_kernel<HT, NT32, IN16, DHT>), dim3(B * H), dim3(XNT), smem, s, q, kc, vc, S, H, N, out16, out32);
+  hipLaunchKernelGGL((sd_attn_kernel<HT, NT32, IN16, DHT>), dim3(B * H), dim3(XNT), smem, s, q, kc, vc, S, H, N, out16, out32, ntok);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
@@ -306,17 +308,17 @@ bool lin_xattn_supported(int dh) { return dh == DH || dh == DH2; }
 
 // q_fmt: 0 = fp32 q rows, 1 / 2 = bf16 / fp16 rows; h16: operand format of the MFMAs and of out16 (MDM_H16_*)
 int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, int S, int H, int dh, int N, uint16_t* out16,
-            float* out32, int h16, hipStream_t s) {
+            float* out32, int h16, hipStream_t s, const int32_t* ntok) {
   const int q_bf16 = q_fmt != 0;
   if (q_fmt && q_fmt != h16) return MDM_ERR_ARG;
   if (!xattn_supported(dh, N)) return MDM_ERR_UNSUPPORTED;
   if (!q || !kc || !vc || (!out16 && !out32)) return MDM_ERR_ARG;
   const bool f16 = h16 == MDM_H16_F16;
 #define MDM_SD(NT, DHT)                                                                                                     \
-  (f16 ? (q_bf16 ? launch_sd<HF, NT, true, DHT>(q, kc, vc, B, S, H, N, out16, out32, s)                                     \
-                 : launch_sd<HF, NT, false, DHT>(q, kc, vc, B, S, H, N, out16, out32, s))                                   \
-       : (q_bf16 ? launch_sd<HB, NT, true, DHT>(q, kc, vc, B, S, H, N, out16, out32, s)                                     \
-                 : launch_sd<HB, NT, false, DHT>(q, kc, vc, B, S, H, N, out16, out32, s)))
+  (f16 ? (q_bf16 ? launch_sd<HF, NT, true, DHT>(q, kc, vc, B, S, H, N, out16, out32, s, ntok)                                     \
+                 : launch_sd<HF, NT, false, DHT>(q, kc, vc, B, S, H, N, out16, out32, s, ntok))                                   \
+       : (q_bf16 ? launch_sd<HB, NT, true, DHT>(q, kc, vc, B, S, H, N, out16, out32, s, ntok)                                     \
+                 : launch_sd<HB, NT, false, DHT>(q, kc, vc, B, S, H, N, out16, out32, s, ntok)))
   if (dh == DH2) return N <= 32 ? MDM_SD(1, 256) : (N <= 64 ? MDM_SD(2, 256) : MDM_SD(3, 256));
   return N <= 32 ? MDM_SD(1, 128) : (N <= 64 ? MDM_SD(2, 128) : MDM_SD(3, 128));
 #undef MDM_SD

@@ -307,6 +307,8 @@ class _StepRunner:
                  streams: int = 0):
         self.d, self.model, self.mode = diff, model, mode
         self.philox = None  # (seed, global index of row 0): per-step noise from the counter-based device generator
+        self.ntok = None    # per-row text token counts when the cond / uncond captions tokenise to different lengths
+        self.tcache = None
         self.nstreams = int(streams) if streams else int(getattr(model, "sampler_streams", 1))
         self.cfg_scale, self.eta, self.clip, self.use_graph = float(cfg_scale), float(eta), bool(clip), use_graph
         if device is None:
@@ -336,12 +338,20 @@ class _StepRunner:
             self.R = 2 * B
             # A real tokenizer gives the empty caption fewer tokens than the captions (N = 8 + 2 vs 8 + longest caption,
             # text_encoder.py:25-43) and the reference's cross-attention has no text mask, so the shorter side must NOT
-            # be padded: then the two halves run as two B-row forwards with their own text caches (split_halves).
-            self.split_halves = uo.shape[1] != xo.shape[1]
+            # see padding.  Default: the shorter half is padded with zero rows and the text cache carries a per-row token
+            # count (MdmTextCache.ntok) under which those rows have weight exactly 0 in both cross-attentions -- still ONE
+            # forward of 2B rows.  model.ragged_text = "split": two B-row forwards with their own text caches instead.
+            ragged = uo.shape[1] != xo.shape[1]
+            self.split_halves = ragged and (getattr(model, "ragged_text", "mask") == "split" or not hasattr(model, "prepare_text"))
             if self.split_halves:
                 self.xp, self.xo = None, None
                 self.halves = [(xp.contiguous(), xo.contiguous()), (up.contiguous(), uo.contiguous())]
             else:
+                if ragged:
+                    nmax = max(xo.shape[1], uo.shape[1])
+                    self.ntok = [xo.shape[1]] * B + [uo.shape[1]] * B
+                    xo = torch.nn.functional.pad(xo, (0, 0, 0, nmax - xo.shape[1]))
+                    uo = torch.nn.functional.pad(uo, (0, 0, 0, nmax - uo.shape[1]))
                 self.xp = torch.cat([xp, up], 0).contiguous()
                 self.xo = torch.cat([xo, uo], 0).contiguous()
         else:
@@ -385,7 +395,8 @@ class _StepRunner:
                 xp_c = self.xp[sl].contiguous()
                 self.chunks.append(dict(
                     sl=sl, xp=xp_c, xo=xo_c, len=self.len2[sl].contiguous(),
-                    tc=model.prepare_text(xo_c, private=True), stem=model.stem_cache(diff.num_timesteps, xp_c),
+                    tc=model.prepare_text(xo_c, private=True, ntok=self.ntok[sl] if self.ntok else None),
+                    stem=model.stem_cache(diff.num_timesteps, xp_c),
                     ws=model.new_workspace(n, T, xo_c.shape[1]), stream=c))
 
     # one step on the current stream: reads self.xx[:B] (x_t), writes x_{t-1} back into it
@@ -413,6 +424,11 @@ class _StepRunner:
                                out=self.eps[ch["sl"]], stem_cache=ch["stem"], text_cache=ch["tc"], workspace=ch["ws"])
             for st in self.side:
                 main.wait_stream(st)  # join before the guidance / posterior update
+        elif self.ntok is not None:  # ragged captions: a private text cache with per-row token counts
+            if self.tcache is None:
+                self.tcache = self.model.prepare_text(self.xo, private=True, ntok=self.ntok)
+            self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps, stem_cache=self.stem,
+                       text_cache=self.tcache)
         elif self.stem is not None:
             self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps, stem_cache=self.stem)
         else:

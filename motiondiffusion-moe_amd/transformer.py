@@ -280,15 +280,25 @@ class MotionTransformer(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def prepare_text(self, xf_out: torch.Tensor, private: bool = False):
+    def prepare_text(self, xf_out: torch.Tensor, private: bool = False, ntok=None):
         """Build (or fetch) the text-side cache for this xf_out [B,N,Dt].  ``private=True`` returns a cache object
-        owned by the caller (pass it back as ``forward(..., text_cache=)``) instead of the module's single slot."""
+        owned by the caller (pass it back as ``forward(..., text_cache=)``) instead of the module's single slot.
+        ``ntok`` (optional, one int per sample, 1 <= ntok[b] <= N): sample b's own token count; its rows past that are
+        padding that neither cross-attention sees (include/mdm_hip.h: MdmTextCache.ntok)."""
         pm = self.pack()
         xf_out = xf_out.detach().to(device=self.device, dtype=torch.float32).contiguous()
         B, N, Dt = xf_out.shape
         if Dt != self.text_latent_dim:
             raise ValueError(f"xf_out last dim {Dt} != text_latent_dim {self.text_latent_dim}")
-        key = (xf_out.data_ptr(), xf_out._version, B, N, self.precision)
+        nt_key = None
+        if ntok is not None:
+            nt_host = [int(v) for v in (ntok.tolist() if torch.is_tensor(ntok) else ntok)]
+            if len(nt_host) != B or min(nt_host) < 1 or max(nt_host) > N:
+                raise ValueError("ntok must hold one token count in [1, N] per sample")
+            nt_key = tuple(nt_host)
+            if all(v == N for v in nt_host):
+                ntok, nt_key = None, None
+        key = (xf_out.data_ptr(), xf_out._version, B, N, self.precision, nt_key)
         if not private and self._text_cache is not None and self._text_cache["key"] == key:
             return self._text_cache
         D, H, L2 = self.latent_dim, self.num_heads, 2 * self.num_layers
@@ -299,6 +309,10 @@ class MotionTransformer(nn.Module):
         sv = torch.empty((L2, B, N, D), dtype=torch.float32, device=dev)
         tc = L.TextCache()
         tc.lin_at, tc.sd_k, tc.sd_v, tc.B, tc.N = at.data_ptr(), sk.data_ptr(), sv.data_ptr(), B, N
+        nt_dev = None
+        if nt_key is not None:
+            nt_dev = torch.tensor(nt_key, dtype=torch.int32, device=dev)
+            tc.ntok = nt_dev.data_ptr()
         fold = ()
         npass = L.lib().mdm_sd_fold_passes(D, H, N) if self.precision in (L.PREC_BF16, L.PREC_F16, L.PREC_FP8) else 0
         if npass > 0:
@@ -314,7 +328,7 @@ class MotionTransformer(nn.Module):
             L.check(L.lib().mdm_text_cache_build(C.byref(pm.model), C.c_void_p(xf_out.data_ptr()), C.byref(tc),
                                                  C.c_void_p(ws.data_ptr()), C.c_int64(ws.numel()), C.c_int32(self.precision),
                                                  C.c_void_p(L.stream_ptr())), "mdm_text_cache_build")
-        cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out) + fold, "B": B, "N": N, "pm": pm}
+        cache = {"key": key, "tc": tc, "keep": (at, sk, sv, xf_out, nt_dev) + fold, "B": B, "N": N, "pm": pm}
         if not private:
             self._text_cache = cache
         return cache
@@ -347,7 +361,7 @@ class MotionTransformer(nn.Module):
     def forward(self, x: torch.Tensor, timesteps: torch.Tensor, length: torch.Tensor,
                 text: Optional[List[str]] = None, xf_proj=None, xf_out=None, *, forced_routing=None,
                 trace: bool = False, out: Optional[torch.Tensor] = None, stem_cache=None, text_cache=None,
-                workspace: Optional[torch.Tensor] = None):
+                workspace: Optional[torch.Tensor] = None, text_tokens=None):
         if not x.is_cuda:
             raise L.MdmError("MotionTransformer.forward needs GPU tensors: the denoiser runs on HIP kernels only")
         if x.device != self.device:
@@ -365,7 +379,8 @@ class MotionTransformer(nn.Module):
         if self.ephemeral_mode == "resample":
             self.draw_ephemerals()
         pm = self.pack()
-        tcache = text_cache if text_cache is not None and text_cache.get("pm") is pm else self.prepare_text(xf_out)
+        tcache = (text_cache if text_cache is not None and text_cache.get("pm") is pm
+                  else self.prepare_text(xf_out, ntok=text_tokens))
         if tcache["B"] != B:
             raise ValueError("xf_out batch does not match x")
         dev = x.device

@@ -38,11 +38,11 @@ def _setup(B, S, N, precision):
     return m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E)
 
 
-def _run_block(m, block, h, sc, length, xf, forced=None):
+def _run_block(m, block, h, sc, length, xf, forced=None, ntok=None):
     L = pkg("_lib")
     pm = m.pack()
     B, S, D = h.shape
-    tcache = m.prepare_text(xf.cuda())
+    tcache = m.prepare_text(xf.cuda(), ntok=ntok)
     ws = m._workspace(B, S, xf.shape[1])
     hd, scd, ld = h.cuda().contiguous(), sc.cuda().contiguous(), length.to(torch.int32).cuda()
     out = torch.empty_like(hd)
@@ -145,6 +145,49 @@ def test_sd_fold_matches_unfolded_chain(S, N, B):
     print(f"S={S} N={N}: folded {e_f:.2e}  chain {e_c:.2e}  folded-vs-chain {d:.2e}")
     assert e_f < TOL[1] and e_c < TOL[1]
     assert not torch.equal(folded, chain)  # the knob really selects two different code paths
+
+
+@pytest.mark.parametrize("precision,knob", [(3, 0), (2, 0), (2, 22), (1, 24), (2, 24)])
+@pytest.mark.parametrize("S,N,counts", [(98, 28, [28, 9, 17]), (40, 64, [1, 64, 33]), (196, 85, [85, 10, 47])])
+def test_per_sample_token_counts_equal_each_sample_run_with_its_own_tokens(S, N, counts, precision, knob):
+    """MdmTextCache.ntok: samples whose captions have different token counts travel in one batch, padded to N rows; both
+    text cross-attentions must give every sample what it gets when run alone with exactly its own tokens (what the reference
+    computes: it has no text mask, so it can only run such samples in separate forwards), whatever the padding rows hold.
+    Paths: fp32-grade chain (row softmax), folded kernel (knob 24 forces it), attention-core kernel (knob 22), and against
+    the oracle on the sample's own tokens."""
+    B = len(counts)
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, precision)
+    L = pkg("_lib")
+    synth = pkg("synth")
+    length = torch.tensor([S, max(1, S - 13), S][:B])
+    pad = synth.uniform_pm1(tuple(xf.shape), "blk.pad", N) * 9.0   # the padding rows hold junk, not zeros
+    xf_pad = xf.clone()
+    for b, n in enumerate(counts):
+        xf_pad[b, n:] = pad[b, n:]
+    tol = {3: 2e-5, 2: 2e-3, 1: 1.5e-2}[precision]
+    L.lib().mdm_set_gemm_variant(knob)
+    try:
+        for block, ref_fn in ((L.BLOCK_CROSS, "cross"), (L.BLOCK_SDCROSS, "sd")):
+            got = _run_block(m, block, h, sc, length, xf_pad, ntok=counts)
+            assert torch.isfinite(got).all()
+            for b, n in enumerate(counts):
+                sl = slice(b, b + 1)
+                alone = _run_block(m, block, h[sl], sc[:, sl], length[sl], xf[sl, :n].contiguous())
+                with torch.no_grad():
+                    if ref_fn == "cross":
+                        ref = R.gated_cross_attention(h[sl], xf[sl, :n], emb[sl], sd, pre + ".cross_attn", H, eph["low.0.cross_style"])
+                    else:
+                        ref = R.softmax_cross_ffn(h[sl], xf[sl, :n], sd, pre + ".sd_cross_attn", H)
+                e_alone, e_ref = rel_inf(got[sl], alone), rel_inf(got[sl], ref)
+                print(f"{ref_fn} S={S} N={N} n={n} precision {precision} knob {knob}: vs alone {e_alone:.2e}, vs oracle {e_ref:.2e}")
+                assert e_alone < tol and e_ref < TOL[precision]
+        # an unmasked run over the junk rows must differ: the counts are really applied
+        junk = _run_block(m, L.BLOCK_SDCROSS, h, sc, length, xf_pad)
+        assert rel_inf(junk, got) > 10 * tol or all(n == N for n in counts)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    with pytest.raises(ValueError):
+        m.prepare_text(xf_pad.cuda(), ntok=[0] * B)
 
 
 @pytest.mark.parametrize("precision", [3, 1, 2, 4])

@@ -244,11 +244,14 @@ def test_non_finite_row_gives_nan_output_not_a_fault(precision):
         m(g["x"].cuda(), *args, forced_routing=torch.full((2, 4 * B * T), 99, dtype=torch.int32), **kw)
 
 
-def test_cfg_halves_with_different_token_counts_match_the_oracle():
-    """The empty caption tokenises to fewer tokens than the captions: the guided step then runs cond and
-    uncond as two forwards with their own text caches and must equal the oracle's two-forward CFG step."""
+@pytest.mark.parametrize("ragged_text", ["mask", "split"])
+def test_cfg_halves_with_different_token_counts_match_the_oracle(ragged_text):
+    """The empty caption tokenises to fewer tokens than the captions.  Default ("mask"): the shorter half is padded
+    and the text cache carries per-row token counts -- still one forward of 2B rows; "split": cond and uncond as two forwards
+    with their own text caches.  Either must equal the oracle's two-forward CFG step."""
     g, meta = load_golden("fwd_small_dims")
     m, (sd, eph, proj, mcfg) = build_module(meta, precision=3)
+    m.ragged_text = ragged_text
     D = pkg("diffusion")
     synth = pkg("synth")
     B, T, Fe = g["x"].shape
@@ -272,6 +275,10 @@ def test_cfg_halves_with_different_token_counts_match_the_oracle():
     # and through the captured loop (graph replay of two forwards per step)
     y = diff.p_sample_loop_with_cfg(m, (B, T, Fe), noise=g["x"].cuda(), clip_denoised=False, model_kwargs=kw, cfg_scale=scale, seed=11)
     assert torch.isfinite(y).all()
+    if ragged_text == "mask":   # the two ways of running ragged halves give the same trajectory
+        m.ragged_text = "split"
+        y2 = diff.p_sample_loop_with_cfg(m, (B, T, Fe), noise=g["x"].cuda(), clip_denoised=False, model_kwargs=kw, cfg_scale=scale, seed=11)
+        assert rel_inf(y.cpu(), y2.cpu()) < 1e-3
 
 
 def test_wrong_device_inputs_raise():
