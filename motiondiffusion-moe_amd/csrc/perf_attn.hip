@@ -8,8 +8,8 @@
 //   Q:  q rows -> LN -> L2 -> MFMA with P^T with the operands swapped, so the feature accumulator (4 consecutive m per
 //       lane, one t per lane) IS the B operand of the next MFMA after exp + bf16 packing (the k-slot order is matched on
 //       the KV^T side by two 8-byte reads); same-t denominator from kphi^T; num / den; LN(dh); bf16 rows out.
-// LDS: kphi^T and v^T 128 x (TP+8) bf16 each (row stride/16 B odd => conflict-free fragment reads), KV^T 128 x 136;
-// P^T (128 x 136) time-shares the v^T region.  153,600 B at T = 196.
+// LDS: kphi^T and v^T 128 x (TP+8) 16-bit each (row stride/16 B odd => conflict-free fragment reads), P^T 128 x 136 resident;
+// KV^T (128 x 136) takes the v^T region once v^T is dead.  153,600 B at T = 196.
 #include "kernels.h"
 
 namespace mdm {
@@ -44,13 +44,12 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int D = H * DH;
   const int ntile = (S + 15) >> 4, SP = ntile * 16, TP = (S + 31) & ~31, TS = TP + 8;
-  const int vreg = (DH * TS > MF * PS) ? DH * TS : MF * PS;  // v^T region also hosts P^T
+  const int vreg = (DH * TS > DH * PS) ? DH * TS : DH * PS;  // the v^T region takes the KV^T state once v^T is dead
   uint16_t* kT = smem;
   uint16_t* vT = smem + MF * TS;
-  uint16_t* KV = vT + vreg;
-  uint16_t* PTl = vT;
-  int nvalid = len[b];
-  nvalid = nvalid < S ? nvalid : S;
+  uint16_t* PTl = vT + vreg;  // P^T stays resident: the q features need it again (a second load from L2 sat between two
+  uint16_t* KV = vT;          // barriers in the middle of the kernel)
+  const int nvalid = min(len[b], S);
 
   // LayerNorm gain/bias at this lane's input positions k = 32*ks + 8*q + j
   float gw[32], gb[32];
@@ -65,40 +64,38 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
     }
   }
 
-  auto load_PT = [&]() {  // 128 x 128 bf16 = 2048 16-B chunks, 4 per thread: all loads in flight, then the LDS writes
-    uint4 tmp[2048 / NTH];
-#pragma unroll
-    for (int k = 0; k < 2048 / NTH; ++k) {
-      const int i = tid + NTH * k;
-      tmp[k] = *(const uint4*)(PT + (int64_t)(i >> 4) * ldp + (i & 15) * 8);
-    }
-#pragma unroll
-    for (int k = 0; k < 2048 / NTH; ++k) {
-      const int i = tid + NTH * k;
-      *(uint4*)(PTl + (i >> 4) * PS + (i & 15) * 8) = tmp[k];
-    }
+  // 128 x 128 16-bit = 2048 16-B chunks, 4 per thread: all loads in flight, then the LDS writes (named registers: an array
+  // captured by a lambda keeps its stack slot, and a kernel with a private segment pays for it at every wave launch)
+  static_assert(2048 / NTH == 4, "four chunks per thread");
+  auto load_PT = [&]() __attribute__((always_inline)) {
+    const uint16_t* src = PT + (int64_t)(tid >> 4) * ldp + (tid & 15) * 8;
+    const uint4 t0 = *(const uint4*)(src), t1 = *(const uint4*)(src + (int64_t)(NTH >> 4) * ldp);
+    const uint4 t2 = *(const uint4*)(src + (int64_t)(2 * NTH >> 4) * ldp), t3 = *(const uint4*)(src + (int64_t)(3 * NTH >> 4) * ldp);
+    uint16_t* dst = PTl + (tid >> 4) * PS + (tid & 15) * 8;
+    *(uint4*)(dst) = t0;
+    *(uint4*)(dst + (NTH >> 4) * PS) = t1;
+    *(uint4*)(dst + (2 * NTH >> 4) * PS) = t2;
+    *(uint4*)(dst + (3 * NTH >> 4) * PS) = t3;
   };
   // A wave owns tiles wid, wid+8 (S <= 224 -> 14 tiles).  All of its k and v rows are requested up front and
   // its q rows as soon as the k registers are free: one global round trip per phase instead of one per tile.
   constexpr int MAXT = 2;
-  struct Raw { uint4 u[4]; };  // row t0 + r16, elements k = 32*ks + 8*q + j, bf16
-  auto raw_load = [&](int which, int tile) {
-    Raw r;
+  // raw row t0 + r16, elements k = 32*ks + 8*q + j, 16-bit: uint4 u[4]
+  auto raw_load = [&](int which, int tile, uint4 (&u)[4]) __attribute__((always_inline)) {
     const int t = tile * 16 + r16;
     const int tc = t < S ? t : S - 1;
     const uint16_t* p = qkv + ((int64_t)(b * S + tc)) * 3 * D + which * D + h * DH + 8 * q;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) r.u[ks] = *(const uint4*)(p + 32 * ks);
-    return r;
+    for (int ks = 0; ks < 4; ++ks) u[ks] = *(const uint4*)(p + 32 * ks);
   };
   // LN over head_dim (+ L2 normalise) -> x[32]
-  auto normalize = [&](const Raw& r, bool l2, float (&x)[32]) {
+  auto normalize = [&](const uint4 (&u)[4], bool l2, float (&x)[32]) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      x[8 * ks + 0] = HT::lo(r.u[ks].x), x[8 * ks + 1] = HT::hi(r.u[ks].x);
-      x[8 * ks + 2] = HT::lo(r.u[ks].y), x[8 * ks + 3] = HT::hi(r.u[ks].y);
-      x[8 * ks + 4] = HT::lo(r.u[ks].z), x[8 * ks + 5] = HT::hi(r.u[ks].z);
-      x[8 * ks + 6] = HT::lo(r.u[ks].w), x[8 * ks + 7] = HT::hi(r.u[ks].w);
+      x[8 * ks + 0] = HT::lo(u[ks].x), x[8 * ks + 1] = HT::hi(u[ks].x);
+      x[8 * ks + 2] = HT::lo(u[ks].y), x[8 * ks + 3] = HT::hi(u[ks].y);
+      x[8 * ks + 4] = HT::lo(u[ks].z), x[8 * ks + 5] = HT::hi(u[ks].z);
+      x[8 * ks + 6] = HT::lo(u[ks].w), x[8 * ks + 7] = HT::hi(u[ks].w);
     }
     float s = 0.f;
 #pragma unroll
@@ -122,13 +119,13 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
       for (int i = 0; i < 32; ++i) x[i] *= inv;
     }
   };
-  Raw kq[MAXT], vr[MAXT];
+  uint4 kq[MAXT][4], vr[MAXT][4];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int tile = wid + NW * i;
     if (tile < ntile) {
-      kq[i] = raw_load(1, tile);
-      vr[i] = raw_load(2, tile);
+      raw_load(1, tile, kq[i]);
+      raw_load(2, tile, vr[i]);
     }
   }
 
@@ -139,7 +136,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
     const int tile = wid + NW * it;
-    if (tile >= ntile) break;
+    if (tile >= ntile) continue;  // (not break: the loop must unroll completely, or kq[] / vr[] live in scratch memory)
     const int t0 = tile * 16;
     float x[32];
     normalize(kq[it], true, x);
@@ -169,14 +166,14 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
   }
 #pragma unroll
   for (int i = 0; i < MAXT; ++i)  // k registers are free: request the q rows now, they land during the V / KV phases
-    if (wid + NW * i < ntile) kq[i] = raw_load(0, wid + NW * i);
-  __syncthreads();  // kphi^T complete, P^T reads done
+    if (wid + NW * i < ntile) raw_load(0, wid + NW * i, kq[i]);
+  __syncthreads();  // kphi^T complete
 
   // ---- V: v^T[d][t] ------------------------------------------------------------------------------
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
     const int tile = wid + NW * it;
-    if (tile >= ntile) break;
+    if (tile >= ntile) continue;  // (not break: the loop must unroll completely, or kq[] / vr[] live in scratch memory)
     const int t0 = tile * 16, t = t0 + r16;
     float x[32];
     normalize(vr[it], false, x);
@@ -208,21 +205,20 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = HT::mfma16(a, bf[j], acc[j]);
     }
+    __syncthreads();  // every wave is done reading v^T: its region takes the state
     // D[m][d]: col d = 16j + r16, rows m = 16w + 4q + r  ->  KV^T[d][m..m+3]
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       *(uint2*)(KV + (16 * j + r16) * PS + 16 * wid + 4 * q) =
           make_uint2(HT::pack(0.1f * acc[j][0], 0.1f * acc[j][1]), HT::pack(0.1f * acc[j][2], 0.1f * acc[j][3]));
   }
-  __syncthreads();  // v^T dead: its region takes P^T again
-  load_PT();
   __syncthreads();
 
   // ---- Q: features -> denominator -> num = qphi KV -> LN -> out -------------------------------------
 #pragma unroll
   for (int it = 0; it < MAXT; ++it) {
     const int tile = wid + NW * it;
-    if (tile >= ntile) break;
+    if (tile >= ntile) continue;  // (not break: the loop must unroll completely, or kq[] / vr[] live in scratch memory)
     const int t0 = tile * 16, t = t0 + r16;
     float x[32];
     normalize(kq[it], true, x);
