@@ -241,12 +241,12 @@ def mode_table(a, m_main, inputs, host, diff, kw, dev, main_prec, main_ms, steps
         else:
             m, _, _ = build_model(a.config, dev, prec, B, T, xf_out.shape[1], seed=0)
         dump = torch.full((L2, 2, B * T, 2), -1, dtype=torch.int32, device=dev)
-        L.lib().mdm_route_dump(C.c_void_p(dump.data_ptr()))
+        L.lib().mdm_route_dump(C.c_void_p(dump.data_ptr()), C.c_int64(dump.numel()))
         try:  # the dump pointer is process-global in the library: never leave it pointing at a freed tensor
             outs[prec] = m(xd, t, ld, xf_proj=kw["xf_proj"], xf_out=kw["xf_out"]).clone()
             torch.cuda.synchronize()
         finally:
-            L.lib().mdm_route_dump(C.c_void_p(0))
+            L.lib().mdm_route_dump(C.c_void_p(0), C.c_int64(0))
         routes[prec] = dump.sort(-1).values
         if prec == main_prec:
             ms = main_ms

@@ -422,8 +422,9 @@ int mdm_debug_stamps(uint64_t* out16);
 int mdm_probe_enable(int32_t enable);
 /* Test aid: while buf is non-NULL, mdm_denoiser_forward copies the router's decisions into it, laid out like
  * forced_routing: int32 [2L][2 branches][B*S_layer (padded to B*T)][2] (mdm_block_forward(MDM_BLOCK_MOE): one layer's worth).
- * Used to count routing flips against the oracle; pass NULL to switch it off. */
-int mdm_route_dump(int32_t* buf);
+ * capacity = int32 elements buf holds: a forward that needs more (2L * 4 * B * T) returns MDM_ERR_ARG instead of writing past it.
+ * Used to count routing flips against the oracle; pass NULL to switch it off.  Process-global, not thread-safe. */
+int mdm_route_dump(int32_t* buf, int64_t capacity);
 /* Number of passes (of <= 128 folded text columns, whole heads) the fused text cross-attention takes for H heads and N text
  * tokens, 0 when the folded path is not taken (D != 512, or more than two passes: N > 64 at H = 4, where the GEMM chain
  * measures faster).  Sizes the optional MdmTextCache buffers:

@@ -56,11 +56,13 @@ __device__ __forceinline__ void lds_barrier() {
 
 // Which tile this workgroup owns: groups are cut into ceil(rows / tile_h) tiles of equal height (a multiple of 16).  Lane e of
 // every wave looks at group e (at most 64 groups); mt = tile index; false = no such tile.
-__device__ __forceinline__ bool find_tile(const MdmMlpDesc& g, int tile_h, int lane, int mt, int& row0, int& row_end, int& grp) {
+// gtab: the group offsets goff[0 .. ng] (or {0, M}) in LDS, copied once per workgroup (a persistent workgroup looks tiles up many
+// times; from global memory every lookup is a dependent L2 round trip in front of the tile)
+__device__ __forceinline__ bool find_tile(const MdmMlpDesc& g, const int* gtab, int tile_h, int lane, int mt, int& row0, int& row_end,
+                                          int& grp) {
   const int ng = g.goff ? g.ngroups : 1;
   const int e = lane < ng ? lane : ng - 1;
-  int b = 0, en = g.M;
-  if (g.goff) b = g.goff[e], en = g.goff[e + 1];
+  const int b = gtab[e], en = gtab[e + 1];
   const int rows = lane < ng ? en - b : 0;
   const int t = (rows + tile_h - 1) / tile_h;
   int incl = t;
@@ -238,6 +240,12 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   uint8_t* const ximg = smem;
   uint8_t* const hid = smem + G::XIMG_B;
+  int* const gtab = (int*)(smem + G::SMEM);  // group offsets (<= 65 ints), behind everything the tiles use
+  {
+    const int ng = g.goff ? g.ngroups : 1;
+    if ((int)threadIdx.x <= ng) gtab[threadIdx.x] = g.goff ? g.goff[threadIdx.x] : (threadIdx.x ? g.M : 0);
+    lds_barrier();
+  }
 
   unsigned long long acc[8] = {}, last = 0;
   if constexpr (KO == 9) last = stamp_now();
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
     const int lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     int row0, row_end, grp;
-    if (!find_tile(g, tile_h, lane, mt, row0, row_end, grp)) break;
+    if (!find_tile(g, gtab, tile_h, lane, mt, row0, row_end, grp)) break;
     XSTAMP(0);
 
     const int nchunk = g.F / FC;
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
         const int64_t src = g.gather ? (int64_t)g.gather[srow] : (int64_t)srow;
         xp[hf] = (const uint8_t*)(g.X + src * g.ldx) + (lane & 7) * 16;
       }
-      constexpr int LB = NLINE < 4 ? NLINE : 4;
+      constexpr int LB = NLINE < 8 ? NLINE : 8;  // lines in flight per half row: the accumulators are not live yet
 #pragma unroll
       for (int c0 = 0; c0 < NLINE; c0 += LB) {
         uint4 v[2][LB];
@@ -611,7 +619,7 @@ extern int g_bf16_variant;
 
 template <int RT, int DIN, int KO, int NJ = 4>
 static int launch_stream(const MdmMlpDesc& a, int th, hipStream_t stream) {
-  constexpr int smem = XGeo<RT, DIN, NJ>::SMEM;
+  constexpr int smem = XGeo<RT, DIN, NJ>::SMEM + 512;  // + the group-offset table
   static DevOnce attr;
   if (smem > 65536 && !attr) {
     if (hipFuncSetAttribute((const void*)fused_mlp_stream_kernel<HB, RT, NJ, DIN, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||

@@ -25,6 +25,7 @@ struct Probe {
 };
 Probe g_probe;
 int32_t* g_route_dump = nullptr;  // mdm_route_dump: where the router's top-2 indices of every layer are copied (tests)
+int64_t g_route_cap = 0;           // its capacity in int32 elements: a forward that would write past it is refused
 
 struct Bump {  // carve the caller's workspace; with base == nullptr it only measures
   uint8_t* base;
@@ -834,6 +835,7 @@ int mdm_denoiser_forward(const MdmModel* m, const MdmTextCache* tc, const float*
                  c.bf ? w.xa16 : nullptr));
   MDM_TRY(halve_lengths(length, B, w.len_low, c.s));  // (:341-342)
   c.S = T / 2, c.M = Mlow, c.len = w.len_low;
+  if (g_route_dump && g_route_cap < (int64_t)2 * L * 4 * Mfull) return MDM_ERR_ARG;  // the dump buffer is too small for this forward
   for (int i = 0; i < L; ++i) {  // coarse scale blocks, in place on xa (xb = scratch)      (:343-344)
     const int32_t* fr = forced_routing ? forced_routing + (int64_t)i * 4 * Mfull : nullptr;
     float* tr = trace ? trace + (int64_t)i * 4 * Mfull * D : nullptr;
@@ -878,7 +880,9 @@ int mdm_block_forward(const MdmModel* m, int32_t layer, int32_t block, const Mdm
   switch (block) {
     case MDM_BLOCK_DUAL: return dual_block(c, l, h, c.w.h016, sc, out);
     case MDM_BLOCK_CROSS: return cross_block(c, l, tc_at(*m, *tc, layer), h, sc + 2 * scs, out);
-    case MDM_BLOCK_MOE: return moe_block(c, l, h, sc + 3 * scs, forced_routing, out, nullptr, g_route_dump);
+    case MDM_BLOCK_MOE:
+      if (g_route_dump && g_route_cap < 4 * c.M) return MDM_ERR_ARG;
+      return moe_block(c, l, h, sc + 3 * scs, forced_routing, out, nullptr, g_route_dump);
     case MDM_BLOCK_SDCROSS:
       return sdcross_block(c, l, tc_k(*m, *tc, layer), tc_v(*m, *tc, layer), h, c.w.h016, out, nullptr,
                            tc_fold(*m, *tc, layer));
@@ -1001,8 +1005,9 @@ int mdm_motion_postprocess(const float* motion, const int32_t* length, const flo
 // MdmTextCache.sd_kfold / sd_cb / sd_vfold buffers ([L2][B][passes][128][D], [L2][B][passes][128], [L2][B][passes][D][128])
 int mdm_sd_fold_passes(int32_t D, int32_t H, int32_t N) { return sd_fold_policy(D, H, N); }
 
-int mdm_route_dump(int32_t* buf) {
-  g_route_dump = buf;
+int mdm_route_dump(int32_t* buf, int64_t capacity) {
+  if (buf && capacity <= 0) return MDM_ERR_ARG;
+  g_route_dump = buf, g_route_cap = buf ? capacity : 0;
   return MDM_OK;
 }
 

@@ -63,9 +63,10 @@ class MoEFFNTrainer:
     """One ``MoEMultiBranchFFN`` (latent D, expert hidden F, E experts, time-embedding width Te) in training mode."""
 
     def __init__(self, D: int, F: int, E: int, Te: int, device="cuda", lr: float = 2e-4, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8, max_norm: float = 1.0, dropout: float = 0.0, seed: int = 0):
+                 eps: float = 1e-8, max_norm: float = 1.0, dropout: float = 0.0, seed: int = 0, moe_coef: float = 0.01):
         self.D, self.F, self.E, self.Te = D, F, E, Te
         self.dropout, self.seed = float(dropout), int(seed)  # the mask of iteration i uses seed + i (see forward)
+        self.moe_coef = float(moe_coef)  # weight of the load-balancing loss (transformer.py:265-270: get_total_moe_loss)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.MdmError("the MoE training step runs on the HIP path only (no CPU fallback)")
@@ -135,7 +136,10 @@ class MoEFFNTrainer:
             L.require_cuda(ew, eb)
         ws = self._workspace(B, S)
         out = torch.empty_like(x)
-        mask_seed = (self.seed + self.step_count) & 0xFFFFFFFFFFFFFFFF  # one mask per optimizer iteration
+        # one mask per optimizer iteration AND per data-parallel rank: the masks are keyed on (seed, site, LOCAL row, element),
+        # so ranks that shard a batch must not share a seed or every shard would drop the same pattern
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        mask_seed = (self.seed + self.step_count + rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
         with torch.cuda.device(self.device):
             L.check(L.lib().mdm_moe_ffn_train_forward(
                 C.byref(self.params.struct), self.D, self.F, self.E, self.Te, De, C.c_void_p(L.ptr(ew)), C.c_void_p(L.ptr(eb)),
@@ -205,8 +209,13 @@ class MoEFFNTrainer:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.all_reduce_grads(group)
         self.optimizer_step()
+        # the load-balancing term as the reference logs it: moe_coef * sum over the block's SwitchMoELayers, from THIS
+        # forward's routing (the reference reads buffers that keep accumulating until reset_all_moe_counters is called; the
+        # unscaled per-forward value is returned beside it)
         lb = self.lb_loss.sum()
-        return {"loss_mot_rec": float(loss.item()), "loss_moe": float(lb.item()), "loss_total": float((loss + lb).item())}
+        moe = self.moe_coef * lb
+        return {"loss_mot_rec": float(loss.item()), "loss_moe": float(moe.item()), "loss_moe_unscaled": float(lb.item()),
+                "loss_total": float((loss + moe).item())}
 
 
 def all_reduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:

@@ -169,13 +169,13 @@ def test_configs0_end_to_end_against_the_oracle():
         tr_c, tr_u = {}, {}
         nxt, _ = DR.cfg_step(tb, t, xs, model(xs, tt, True, tr_c), model(xs, tt, False, tr_u), noises[i], scale)
         if i % 7 == 0 or i == steps - 1:  # one HIP step from the oracle's state, its routing dumped
-            lib.mdm_route_dump(C.c_void_p(dump.data_ptr()))
+            lib.mdm_route_dump(C.c_void_p(dump.data_ptr()), C.c_int64(dump.numel()))
             try:
                 out = diff.p_sample_with_cfg(m, xs.cuda(), tt.cuda(), clip_denoised=False, model_kwargs=kw, cfg_scale=scale,
                                              noise=noises[i].cuda())
                 torch.cuda.synchronize()
             finally:
-                lib.mdm_route_dump(C.c_void_p(0))
+                lib.mdm_route_dump(C.c_void_p(0), C.c_int64(0))
             flips, worst_gap = 0, 0.0
             for li, name in enumerate(names):
                 S = T // 2 if li < L else T

@@ -31,12 +31,12 @@ class RouteDump:
         self.buf = torch.full((L2, 2, B * T, 2), -1, dtype=torch.int32, device="cuda")
 
     def __enter__(self):
-        pkg("_lib").lib().mdm_route_dump(C.c_void_p(self.buf.data_ptr()))
+        pkg("_lib").lib().mdm_route_dump(C.c_void_p(self.buf.data_ptr()), C.c_int64(self.buf.numel()))
         return self
 
     def __exit__(self, *a):
         torch.cuda.synchronize()
-        pkg("_lib").lib().mdm_route_dump(C.c_void_p(0))
+        pkg("_lib").lib().mdm_route_dump(C.c_void_p(0), C.c_int64(0))
 
     def layer(self, li, M):
         """(2, M, 2) decisions of layer li, whose token count is M (the buffer is strided for the full scale)."""
