@@ -63,6 +63,22 @@ int gemm_fp8(const GemmArgs& a, hipStream_t stream);  // gemm8.hip: e4m3 operand
 // mlp_stream.hip: the same MLP with the weights streamed global -> registers from a packed fragment stream
 bool fused_mlp_stream_supported(const MdmMlpDesc& a);
 int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream);
+// the Performer tail behind the proj_out pair, in the pair's launch (csrc/mlp_stream.hip: pair_tail)
+struct PairTail {
+  const float *pw, *pb;   // post_norm
+  const float *sw, *sb;   // style norm
+  const float* sc;        // (B, 2 D) scale | shift
+  int S;                  // frames per sample
+  const uint16_t* ws;     // weight stream of out_layers.2 (mdm_gemm_stream_pack)
+  const float* bias;
+  const float* resid;     // [M, D]
+  float out_scale;
+  float* out;             // fp32 [M, D]
+  const float *lw, *lb;   // optional LayerNorm of the output rows ...
+  uint16_t* ln16;         // ... written here as 16-bit rows
+};
+bool fused_pair_style_supported(const MdmMlpDesc& a);
+int fused_pair_style(const MdmMlpDesc& a, const PairTail& t, hipStream_t stream);
 int64_t mlp_stream_elems(int G, int F, int Din, int Dout);
 int mlp_stream_pack(const float* w1, const float* w2, int G, int F, int Din, int Dout, int h16, uint16_t* out, hipStream_t stream);
 // style_gemm.hip: stylization input + its D x D Linear + the residual in one launch (streamed weights)

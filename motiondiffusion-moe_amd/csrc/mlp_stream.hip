@@ -33,6 +33,7 @@
 
 #include "gemm.h"
 #include "kernels.h"
+#include "row.h"
 
 namespace mdm {
 namespace {
@@ -193,7 +194,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     }                                              \
   } while (0)
 
-template <int RT, int DIN, int NJ = 4>
+template <int RT, int DIN, int NJ = 4, bool TAIL = false>
 struct XGeo {
   static constexpr int ROWS = RT * 16;
   static constexpr int XROW_B = DIN * 2;     // X image: 16-B chunk c of row m at slot c ^ (m & 15)
@@ -202,7 +203,9 @@ struct XGeo {
   static constexpr int IMG_B = XIMG_B + HID_B;
   // epilogue staging: the whole 16-bit tile [ROWS][128 NJ], or at least one fp32 row tile [16][128 NJ]
   static constexpr int STG_B = ROWS * NJ * 256 > NJ * 8192 ? ROWS * NJ * 256 : NJ * 8192;
-  static constexpr int SMEM = IMG_B > STG_B ? IMG_B : STG_B;
+  static constexpr int TAIL_B = ROWS * NJ * 512;  // the stylization tail stages whole fp32 rows [ROWS][128 NJ]
+  static constexpr int SMEM0 = IMG_B > STG_B ? IMG_B : STG_B;
+  static constexpr int SMEM = (TAIL && TAIL_B > SMEM0) ? TAIL_B : SMEM0;
 };
 
 // The GELU of one value pair in two pieces (so that a piece fits beside the four MFMAs of one A fragment): gelu_sig2 of
@@ -223,13 +226,151 @@ __device__ __forceinline__ f32x2 gelu_part_b(f32x2 v, f32x2 e) {
   return (f32x2){v[0] * __builtin_amdgcn_rcpf(e[0] + 1.0f), v[1] * __builtin_amdgcn_rcpf(e[1] + 1.0f)};
 }
 
+// ---- the Performer tail behind the proj_out pair (fast_attention.py:165-178), in the same launch ---------------------------
+// Per 16 RT-row tile, with the pair's result y (+ b2) in the accumulators:
+//   rows as 16-bit (what the unfused path stores and reloads) -> LDS image -> row phase exactly as csrc/style_gemm.hip / rowwise.hip
+//   style_in (one wave per row: post_norm, L2 norm * sqrt(D), style norm, (1 + scale) / shift, SiLU) in place -> out_layers.2 with
+//   Wout streamed global -> registers -> (y + b) * out_scale + resid staged as fp32 rows -> one wave per row: fp32 row out and,
+//   optionally, LayerNorm(row) as 16-bit (the pre_norm of the block that follows: one more launch saved).
+// Every row goes through the same arithmetic as in the unfused launches; the results agree to rounding, not bit for bit (the two
+// compilations contract multiply-adds differently, and a last-bit difference before the 16-bit image flips a rounding there).
+
+template <typename HT, int RT, int NR>
+__device__ __forceinline__ void pair_tail(const PairTail& st, f32x4 (&y)[RT][4], typename HT::frag_t (&R)[NR], uint8_t* smem, int row0,
+                                          int row_end, int tid, int wn) {
+  typedef typename HT::frag_t frag_t;
+  typedef Row<8, true> R8;
+  constexpr int D = 512, FMT = HT::FMT, RPW = 2 * RT;  // rows per wave in the row phases
+  const int lane = tid & 63, frow = lane & 15, fq = lane >> 4;
+  // the ring's first fragments of Wout are requested now: they land during the row phase
+  const uint8_t* wp = (const uint8_t*)st.ws + (int64_t)wn * 64 * 1024 + lane * 16;
+#pragma unroll
+  for (int f = 0; f < NR; ++f) R[f] = *(const frag_t*)(wp + f * 1024);
+  wp += NR * 1024;
+  lds_barrier();  // every wave is past its last reads of the X rows and of the hidden image: the LDS is free
+  // rows as 16-bit in the MFMA image layout (16-B chunk c of row r at slot c ^ (r & 15))
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const int ml = i * 16 + frow;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = wn * 64 + 16 * j + 4 * fq;
+      const f32x4 v = y[i][j];
+      *(uint2*)(smem + ml * 1024 + ((((n >> 3) ^ (ml & 15))) << 4) + ((n >> 2) & 1) * 8) =
+          make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
+    }
+  }
+  lds_barrier();
+  {
+    R8 pww, pbb, sww, sbb;
+    pww.load(st.pw, D, lane), pbb.load(st.pb, D, lane);
+    sww.load(st.sw, D, lane), sbb.load(st.sb, D, lane);
+#pragma unroll 2
+    for (int q = 0; q < RPW; ++q) {
+      const int rl = RPW * wn + q;
+      int row = row0 + rl;
+      row = row < row_end ? row : row_end - 1;  // rows past the tile's end: never stored
+      const float* scb = st.sc + (int64_t)(row / st.S) * 2 * D;
+      R8 r, scale, shift;
+      scale.load(scb, D, lane);
+      shift.load(scb + D, D, lane);
+      // lane holds columns 4 l .. 4 l + 3 and 256 + 4 l ..: 8 bytes each, 16-B chunks (l >> 1) and 32 + (l >> 1), half l & 1
+      uint8_t* ir = smem + rl * 1024 + (lane & 1) * 8;
+      const uint2 u0 = *(const uint2*)(ir + ((((lane >> 1)) ^ (rl & 15)) << 4));
+      const uint2 u1 = *(const uint2*)(ir + (((32 + (lane >> 1)) ^ (rl & 15)) << 4));
+      r.e[0] = h16_lo_f32(FMT, u0.x), r.e[1] = h16_hi_f32(FMT, u0.x), r.e[2] = h16_lo_f32(FMT, u0.y), r.e[3] = h16_hi_f32(FMT, u0.y);
+      r.e[4] = h16_lo_f32(FMT, u1.x), r.e[5] = h16_hi_f32(FMT, u1.x), r.e[6] = h16_lo_f32(FMT, u1.y), r.e[7] = h16_hi_f32(FMT, u1.y);
+      r.layernorm(pww, pbb, D, lane);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += r.e[j] * r.e[j];
+      const float inv = sqrtf((float)D) / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.e[j] *= inv;
+      r.layernorm(sww, sbb, D, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.e[j] = silu(r.e[j] * (1.f + scale.e[j]) + shift.e[j]);
+      *(uint2*)(ir + ((((lane >> 1)) ^ (rl & 15)) << 4)) = make_uint2(HT::pack(r.e[0], r.e[1]), HT::pack(r.e[2], r.e[3]));
+      *(uint2*)(ir + (((32 + (lane >> 1)) ^ (rl & 15)) << 4)) = make_uint2(HT::pack(r.e[4], r.e[5]), HT::pack(r.e[6], r.e[7]));
+    }
+  }
+  lds_barrier();
+  // out_layers.2: y[rows x 64 columns of this wave] = image . Wout^T
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const int xb = frow * 1024 + ((fq ^ frow) << 4);  // (row frow, K step 0); step s reads chunk (4 s) ^ (fq ^ frow)
+    frag_t A[2][RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) A[0][i] = *(const frag_t*)(smem + xb + i * 16384);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) A[(s + 1) & 1][i] = *(const frag_t*)(smem + (xb ^ (64 * ((s + 1) & 3))) + ((s + 1) >> 2) * 256 + i * 16384);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int slot = (s * 4 + j) & (NR - 1);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) y[i][j] = HT::mfma16(R[slot], A[s & 1][i], y[i][j]);
+        R[slot] = *(const frag_t*)(wp + slot * 1024);  // the last NR refills read (and discard) the next wave's / the padding
+        if (slot == NR - 1) wp += NR * 1024;
+      }
+      pin();
+    }
+  }
+  // (y + b) * out_scale staged as fp32 [rows][512] (16-B group c of row r at slot c ^ (r & 31))
+  lds_barrier();
+  float* stg = (float*)smem;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = wn * 64 + 16 * j + 4 * fq;
+    const f32x4 bb = *(const f32x4*)(st.bias + n);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int ml = i * 16 + frow;
+      f32x4 v = y[i][j];
+      v[0] = (v[0] + bb[0]) * st.out_scale, v[1] = (v[1] + bb[1]) * st.out_scale, v[2] = (v[2] + bb[2]) * st.out_scale,
+      v[3] = (v[3] + bb[3]) * st.out_scale;
+      *(f32x4*)(stg + ml * D + (((n >> 2) ^ (ml & 31)) << 2)) = v;
+    }
+  }
+  lds_barrier();
+  {
+    R8 lww, lbb;
+    if (st.ln16) lww.load(st.lw, D, lane), lbb.load(st.lb, D, lane);
+#pragma unroll 2
+    for (int q = 0; q < RPW; ++q) {
+      const int rl = RPW * wn + q;
+      const int64_t m = (int64_t)row0 + rl;
+      if (m >= row_end) continue;  // (wave-uniform)
+      R8 r, x;
+      const f32x4 v0 = *(const f32x4*)(stg + rl * D + ((lane ^ (rl & 31)) << 2));
+      const f32x4 v1 = *(const f32x4*)(stg + rl * D + (((64 + lane) ^ (rl & 31)) << 2));
+      x.load(st.resid + m * D, D, lane);
+      r.e[0] = v0[0] + x.e[0], r.e[1] = v0[1] + x.e[1], r.e[2] = v0[2] + x.e[2], r.e[3] = v0[3] + x.e[3];
+      r.e[4] = v1[0] + x.e[4], r.e[5] = v1[1] + x.e[5], r.e[6] = v1[2] + x.e[6], r.e[7] = v1[3] + x.e[7];
+      r.store(st.out + m * D, D, lane);
+      if (st.ln16) {
+        r.layernorm(lww, lbb, D, lane);
+        r.template store_h16<FMT>(st.ln16 + m * D, D, lane);
+      }
+    }
+  }
+}
+
 // KO: timing-only knock-outs for tools/mlp_ko.py (0 = the real kernel; results are wrong otherwise): 1 no GELU arithmetic,
 // 2 no weight refills, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores; 7 = the real kernel with the erf-form GELU
 // of the LDS-staged kernel; 8 = GELU pieces interleaved with the phase-2 MFMAs of the same wave; 9 = stamped build
 template <typename HT, int RT, int NJ, int DIN, int KO>
-__global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h) {
+__global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h, const PairTail st) {
   typedef typename HT::frag_t frag_t;
-  typedef XGeo<RT, DIN, NJ> G;
+  constexpr bool TAIL = KO == 10;  // the Performer tail (post-norm, stylization, out_layers.2, residual) behind the pair
+  static_assert(!TAIL || (NJ == 4 && DIN == 512 && RT <= 4), "the tail is written for D = 512 rows");
+  typedef XGeo<RT, DIN, NJ, TAIL> G;
   constexpr int NKO = DIN / 128, NLINE = DIN / 64;
   constexpr int NA = 4, PD = NA - 1;  // A-fragment ring: NA registers, PD fragments ahead of the MFMAs
   constexpr int NR = (RT == 4 && NJ == 4 && DIN % 256 == 0) ? 16 : 8;  // weight ring: fragments in flight per wave (16 where the accumulators leave room)
@@ -494,7 +635,9 @@ __global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel
     // the epilogue derives its addresses from an opaque thread id of its own (see above)
     int te = threadIdx.x;
     asm volatile("" : "+v"(te));
-    if constexpr (KO == 9) {
+    if constexpr (TAIL) {
+      pair_tail<HT, RT, NR>(st, y, R, smem, row0, row_end, te, wn);
+    } else if constexpr (KO == 9) {
       MdmMlpDesc g2 = g;
       g2.R2 = nullptr;
       store_tile<HT, RT, NJ, G::SMEM, KO>(g2, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
@@ -618,8 +761,8 @@ int mlp_stream_tile_h(int64_t M, int rt_max) {
 extern int g_bf16_variant;
 
 template <int RT, int DIN, int KO, int NJ = 4>
-static int launch_stream(const MdmMlpDesc& a, int th, hipStream_t stream) {
-  constexpr int smem = XGeo<RT, DIN, NJ>::SMEM + 512;  // + the group-offset table
+static int launch_stream(const MdmMlpDesc& a, int th, hipStream_t stream, const PairTail& tail = PairTail()) {
+  constexpr int smem = XGeo<RT, DIN, NJ, KO == 10>::SMEM + 512;  // + the group-offset table
   static DevOnce attr;
   if (smem > 65536 && !attr) {
     if (hipFuncSetAttribute((const void*)fused_mlp_stream_kernel<HB, RT, NJ, DIN, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
@@ -632,9 +775,9 @@ static int launch_stream(const MdmMlpDesc& a, int th, hipStream_t stream) {
   const int res = device_cus() * (RT <= 2 ? 2 : 1);
   const int grid = tiles < res ? tiles : res;
   if (a.h16 == MDM_H16_F16) {
-    hipLaunchKernelGGL((fused_mlp_stream_kernel<HF, RT, NJ, DIN, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
+    hipLaunchKernelGGL((fused_mlp_stream_kernel<HF, RT, NJ, DIN, KO>), dim3(grid), dim3(NT), smem, stream, a, th, tail);
   } else {
-    hipLaunchKernelGGL((fused_mlp_stream_kernel<HB, RT, NJ, DIN, KO>), dim3(grid), dim3(NT), smem, stream, a, th);
+    hipLaunchKernelGGL((fused_mlp_stream_kernel<HB, RT, NJ, DIN, KO>), dim3(grid), dim3(NT), smem, stream, a, th, tail);
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
@@ -674,6 +817,22 @@ int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream) {
     }
   }
   return launch_by_height<512>(a, stream);
+}
+
+// The Performer's proj_out pair AND its tail (post_norm, stylization, out_layers.2, residual; optionally the LayerNorm of the
+// block that follows) in one launch: a = the pair (dense, D = 512, no residuals / row scale / outputs of its own), t = the tail.
+bool fused_pair_style_supported(const MdmMlpDesc& a) {
+  return fused_mlp_stream_supported(a) && a.Din == 512 && a.Dout == 512 && !a.goff && !a.gather && !a.rowscale && !a.R1 && !a.R2;
+}
+
+int fused_pair_style(const MdmMlpDesc& a, const PairTail& t, hipStream_t stream) {
+  if (!a.X || !fused_pair_style_supported(a)) return MDM_ERR_UNSUPPORTED;
+  if (!t.pw || !t.pb || !t.sw || !t.sb || !t.sc || t.S <= 0 || !t.ws || !t.bias || !t.resid || !t.out || (t.ln16 && (!t.lw || !t.lb)) ||
+      ((uintptr_t)t.ws & 15))
+    return MDM_ERR_ARG;
+  const int th = mlp_stream_tile_h(a.M, 4);  // the tail stages fp32 rows: 64-row tiles at most
+  if (th <= 32) return launch_stream<2, 512, 10>(a, th, stream, t);
+  return launch_stream<4, 512, 10>(a, th, stream, t);
 }
 
 }  // namespace mdm

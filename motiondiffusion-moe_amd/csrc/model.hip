@@ -196,7 +196,10 @@ int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float*
 }
 
 // PerformerSelfAttention (fast_attention.py:137-179): xn = pre_norm(x) already computed; out = x + 0.1*style(...)
-int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const float* sc, float* out) {
+// next_w / next_b / next16 / next_done: optional LayerNorm of `out` for the block that follows, written as 16-bit rows by the
+// fused tail when it runs (*next_done says whether it did)
+int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const float* sc, float* out,
+              const float* next_w = nullptr, const float* next_b = nullptr, uint16_t* next16 = nullptr, bool* next_done = nullptr) {
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H, mf = dh;  // m = min(dh, 256) = dh for dh <= 256
   const Work& w = c.w;
@@ -268,6 +271,17 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     f.X = (const uint16_t*)w.t4, f.ldx = D, f.M = (int)c.M, f.Din = D, f.F = D, f.Dout = D;
     f.b1 = p.proj0_b, f.b2 = p.proj3_b, f.wstream = p.proj_ws, f.wstream_gs = 2 * (int64_t)D * D;
     f.r1_scale = 1.f, f.C16 = (uint16_t*)w.t4, f.ldc = D, f.h16 = c.h16;  // in place: a tile's rows are in LDS before its stores
+    // ... and the tail (post_norm, stylization, out_layers.2, residual, the next block's LayerNorm) in the same launch: the
+    // pair's rows never leave the CU (knob 35: the tail as its own launch)
+    if (p.style.out_ws && g_bf16_variant != 35 && g_bf16_variant != 30 && fused_pair_style_supported(f)) {
+      PairTail t = {};
+      t.pw = p.post_w, t.pb = p.post_b, t.sw = p.style.norm_w, t.sb = p.style.norm_b, t.sc = sc, t.S = c.S;
+      t.ws = p.style.out_ws, t.bias = p.style.out_b, t.resid = x, t.out_scale = 0.1f, t.out = out;
+      if (next16) t.lw = next_w, t.lb = next_b, t.ln16 = next16;
+      MDM_TRY(fused_pair_style(f, t, c.s));
+      if (next_done) *next_done = next16 != nullptr;
+      return MDM_OK;
+    }
     if (fused_mlp_stream_supported(f)) {
       MDM_TRY(fused_mlp_stream(f, c.s));
       pair = true;
@@ -293,8 +307,10 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
   const int64_t scs = (int64_t)c.B * 2 * D;
   // h = pre_norm(x) -> t1 ; local.pre_norm(h) -> t3
   MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, 0, l.local.pre_w, l.local.pre_b, w.t3, fmt16(c), c.s));
-  MDM_TRY(performer(c, l.local, w.t1, act_of(c, w.t3), sc4 + 0 * scs, w.t5));  // local_out -> t5
-  MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
+  bool normed = false;  // local_out -> t5; the fused tail also leaves global.pre_norm(local_out) in t3 (t3 is dead by then)
+  MDM_TRY(performer(c, l.local, w.t1, act_of(c, w.t3), sc4 + 0 * scs, w.t5, l.global.pre_w, l.global.pre_b,
+                    c.bf ? (uint16_t*)w.t3 : nullptr, &normed));
+  if (!normed) MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
   MDM_TRY(performer(c, l.global, w.t5, act_of(c, w.t3), sc4 + 1 * scs, w.t1));  // global_out -> t1
   // skip = GELU(Lin(x)); out = post_norm(skip + 0.1 * global)      (:219-225)
   {

@@ -190,6 +190,31 @@ def test_per_sample_token_counts_equal_each_sample_run_with_its_own_tokens(S, N,
         m.prepare_text(xf_pad.cuda(), ntok=[0] * B)
 
 
+@pytest.mark.parametrize("precision", [2, 1])
+@pytest.mark.parametrize("B,S", [(2, 98), (3, 37), (1, 5), (5, 196)])
+def test_performer_tail_fused_into_the_projection_pair(B, S, precision):
+    """16-bit modes, D = 512: the Performer's proj_out pair, post_norm, stylization, out_layers.2, the residual and the pre_norm of
+    the global branch run in ONE launch (csrc/mlp_stream.hip pair_tail); knob 35 runs the tail as its own launches (style_gemm +
+    ln_chain).  Same arithmetic per row: the block's outputs agree to rounding (a last-bit difference in front of the 16-bit image
+    can flip one 16-bit rounding: 2^-11 of one of 512 terms in fp16, 2^-8 in bf16), also where the last tile is ragged (B * S not
+    a multiple of 16 / 32 / 64), and both agree with the oracle."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, 6, precision)
+    L = pkg("_lib")
+    fused = _run_block(m, L.BLOCK_DUAL, h, sc, length, xf)
+    L.lib().mdm_set_gemm_variant(35)
+    try:
+        split = _run_block(m, L.BLOCK_DUAL, h, sc, length, xf)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    with torch.no_grad():
+        ref = R.dual_self_attention(h, emb, R.src_mask(S, length), sd, pre + ".dual_self_attn", H, eph, proj, "low.0")
+    d, e_f, e_s = rel_inf(fused, split), rel_inf(fused, ref), rel_inf(split, ref)
+    print(f"B={B} S={S} precision {precision}: fused vs split {d:.2e}; vs oracle {e_f:.2e} / {e_s:.2e}")
+    assert torch.isfinite(fused).all()
+    assert d < (2e-4 if precision == 2 else 2e-3)
+    assert e_f < TOL[precision] and e_s < TOL[precision]
+
+
 @pytest.mark.parametrize("precision", [3, 1, 2, 4])
 def test_named_block_entry_points(precision):
     """The per-block C entry points named in SURVEY.md §8(b): the aliases must reproduce mdm_block_forward bit for bit, and
