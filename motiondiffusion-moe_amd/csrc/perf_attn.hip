@@ -3,17 +3,25 @@
 // happens on chip:
 //   K:  k rows -> LN(dh) -> L2 norm -> bf16 A-fragments in registers -> MFMA with P^T (LDS) -> 0.1*exp(clamp) -> mask
 //       -> kphi^T [m][t] in LDS (the accumulator's 4 consecutive t per lane are one 8-byte store)
-//   V:  v rows -> LN(dh) -> v^T [d][t] in LDS
-//   KV: KV^T [d][m] = 0.1 * sum_t v^T kphi^T   (both operands t-contiguous in LDS: plain ds_read_b128 fragments)
+//   V:  v rows -> LN(dh) -> v [t][d] in LDS, row-major (four 16-byte stores per row and lane; 16-B chunk c of row t at slot
+//       c ^ f(t): the stores and the transposing reads below are conflict-free)
+//   KV: KV^T [d][m] = 0.1 * sum_t v[t][d] kphi^T[m][t]   (kphi^T fragments: plain ds_read_b128; the v operand, K-contiguous in t,
+//       comes out of the row-major image through the transposing read ds_read_b64_tr_b16)
 //   Q:  q rows -> LN -> L2 -> MFMA with P^T with the operands swapped, so the feature accumulator (4 consecutive m per
 //       lane, one t per lane) IS the B operand of the next MFMA after exp + bf16 packing (the k-slot order is matched on
-//       the KV^T side by two 8-byte reads); same-t denominator from kphi^T; num / den; LN(dh); bf16 rows out.
-// LDS: kphi^T and v^T 128 x (TP+8) 16-bit each (row stride/16 B odd => conflict-free fragment reads), P^T 128 x 136 resident;
-// KV^T (128 x 136) takes the v^T region once v^T is dead.  153,600 B at T = 196.
+//       the KV^T side by two 8-byte reads); same-t denominator: the lane's four kphi[t][m .. m + 3] come out of kphi^T [m][t] through
+//       the transposing read as well (8 reads per tile instead of 32 two-byte reads); num / den; LN(dh); 16-bit rows out.
+// LDS: kphi^T 128 x (TP+8) 16-bit (row stride/16 B odd => conflict-free fragment reads), v TP x 128, P^T 128 x 136 resident;
+// KV^T (128 x 136) takes the v region once v is dead.  151,552 B at T = 196.
 #include "kernels.h"
 
 namespace mdm {
 namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// v image: 256-byte rows [t][128 d]; 16-byte chunk ch of row `row` sits at chunk ch ^ f(row) (as in perf_attn2.hip)
+__device__ __forceinline__ int voff(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 constexpr int DH = 128, MF = 128, PS = 136, NW = 8, NTH = 64 * NW;  // 8 waves: <= 2 row tiles per wave per phase  // PS: padded row stride (elements) of the 128-wide LDS images
 
@@ -44,9 +52,10 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int D = H * DH;
   const int ntile = (S + 15) >> 4, SP = ntile * 16, TP = (S + 31) & ~31, TS = TP + 8;
-  const int vreg = (DH * TS > DH * PS) ? DH * TS : DH * PS;  // the v^T region takes the KV^T state once v^T is dead
+  const int vreg = (TP * DH > DH * PS) ? TP * DH : DH * PS;  // the v region takes the KV^T state once v is dead
   uint16_t* kT = smem;
   uint16_t* vT = smem + MF * TS;
+  uint8_t* const vimg = (uint8_t*)vT;  // v [TP][128], row-major, swizzled chunks (voff)
   uint16_t* PTl = vT + vreg;  // P^T stays resident: the q features need it again (a second load from L2 sat between two
   uint16_t* KV = vT;          // barriers in the middle of the kernel)
   const int nvalid = min(len[b], S);
@@ -178,17 +187,16 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
     float x[32];
     normalize(vr[it], false, x);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        vT[(32 * ks + 8 * q + j) * TS + t] = t < S ? (uint16_t)(HT::pack(x[8 * ks + j], 0.f) & 0xffff) : (uint16_t)0;
-  }
-  if (TP > SP) {  // zero the K-padding columns of both images
-    for (int i = tid; i < DH * 16; i += NTH) {
-      const int row = i >> 4, c = i & 15;
-      kT[row * TS + SP + c] = 0;
-      vT[row * TS + SP + c] = 0;
+    for (int ks = 0; ks < 4; ++ks) {  // d = 32 ks + 8 q + j: 16-byte chunk 4 ks + q of row t
+      u32x4 u = {HT::pack(x[8 * ks], x[8 * ks + 1]), HT::pack(x[8 * ks + 2], x[8 * ks + 3]), HT::pack(x[8 * ks + 4], x[8 * ks + 5]),
+                 HT::pack(x[8 * ks + 6], x[8 * ks + 7])};
+      if (t >= S) u = (u32x4){0u, 0u, 0u, 0u};
+      *(u32x4*)(vimg + voff(t, 4 * ks + q)) = u;
     }
+  }
+  if (TP > SP) {  // zero the K padding: 16 columns of kphi^T, 16 rows of v
+    for (int i = tid; i < DH * 16; i += NTH) kT[(i >> 4) * TS + SP + (i & 15)] = 0;
+    for (int i = tid; i < 16 * 16; i += NTH) *(u32x4*)(vimg + 256 * (SP + (i >> 4)) + 16 * (i & 15)) = (u32x4){0u, 0u, 0u, 0u};
   }
   __syncthreads();
 
@@ -197,11 +205,20 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
     f32x4 acc[8];  // wave w owns the m tile w (8 waves x 16 = 128 features), all 8 d tiles
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int qp = r16 >> 2, pp = r16 & 3;  // transposing read: this lane addresses row qp, columns 4 pp .. 4 pp + 3 of its group's block
     for (int ks = 0; ks < TP / 32; ++ks) {
       frag_t bf[8];
       const frag_t a = *(const frag_t*)(kT + (16 * wid + r16) * TS + 32 * ks + 8 * q);
+      const int tr0 = 32 * ks + 8 * q + qp;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bf[j] = *(const frag_t*)(vT + (16 * j + r16) * TS + 32 * ks + 8 * q);
+      for (int j = 0; j < 8; ++j) {  // column d = 16 j + r16, k = t = 32 ks + 8 q + 0..7
+        const int ch = 2 * j + (pp >> 1);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(vimg + voff(tr0, ch) + 8 * (pp & 1)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(vimg + voff(tr0 + 4, ch) + 8 * (pp & 1)));
+        bf[j] = __builtin_bit_cast(frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = HT::mfma16(a, bf[j], acc[j]);
     }
@@ -238,13 +255,17 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
     // lane: t = t0 + r16, m = 16*mt + 4q + r
     float den = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < 8; ++mt) {
+      // kphi[t][16 mt + 4 q + 0..3] out of kphi^T [m][t]: the 16 lanes of a group read a 4 x 16 block, each lane gets a column
+      const s16x4 kk = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(kT + (16 * mt + 4 * q + (r16 >> 2)) * TS + t0 + 4 * (r16 & 3)));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float f = 0.1f * exp_fast(fminf(fmaxf(accf[mt][r], -15.f), 15.f));
         accf[mt][r] = f;
-        den += f * HT::one(kT[(16 * mt + 4 * q + r) * TS + t]);  // same-t dot (:81)
+        den += f * HT::one((uint16_t)kk[r]);  // same-t dot (:81)
       }
+    }
     den = fmaxf(quad_sum(den), 1e-6f);
     f32x4 accn[8];
 #pragma unroll
@@ -306,7 +327,7 @@ int perf_attn(const void* qkv, int h16, const uint16_t* PT, int ldp, const float
   if (!perf_attn_supported(dh, S) || (h16 != MDM_H16_BF16 && h16 != MDM_H16_F16)) return MDM_ERR_UNSUPPORTED;
   if (!qkv || !PT || !hn_w || !hn_b || !len || !out || (ldp & 7)) return MDM_ERR_ARG;
   const int TP = (S + 31) & ~31, TS = TP + 8;
-  const int vreg = (DH * TS > MF * PS) ? DH * TS : MF * PS;
+  const int vreg = (TP * DH > MF * PS) ? TP * DH : MF * PS;
   const int smem = (MF * TS + vreg + DH * PS) * 2;
   static DevInt attr;
   if (smem > attr) {
