@@ -76,6 +76,12 @@ struct PairTail {
   float* out;             // fp32 [M, D]
   const float *lw, *lb;   // optional LayerNorm of the output rows ...
   uint16_t* ln16;         // ... written here as 16-bit rows
+  // optional block tail of DualSelfAttentionBlock (fast_attention.py:219-225) when this is its second Performer: with
+  // r = resid + out_scale * style(...) the row becomes out = LN(skip + skip_scale * r; lw, lb) as fp32 (r itself is not written),
+  // and ln16 = LN(out; l2w, l2b) when l2w is set (the pre-norm of the block that follows)
+  const float* skip;      // [M, D] fp32, or NULL
+  float skip_scale;
+  const float *l2w, *l2b;
 };
 bool fused_pair_style_supported(const MdmMlpDesc& a);
 int fused_pair_style(const MdmMlpDesc& a, const PairTail& t, hipStream_t stream);

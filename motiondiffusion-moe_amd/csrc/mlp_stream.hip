@@ -340,23 +340,44 @@ __device__ __forceinline__ void pair_tail(const PairTail& st, f32x4 (&y)[RT][4],
   }
   lds_barrier();
   {
-    R8 lww, lbb;
-    if (st.ln16) lww.load(st.lw, D, lane), lbb.load(st.lb, D, lane);
-#pragma unroll 2
+    // the rows' residual (and skip) operands are all requested first: one memory round trip per wave, not one per row
+    R8 xr[RPW], sk[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+      int64_t m = (int64_t)row0 + RPW * wn + q;
+      m = m < row_end ? m : row_end - 1;
+      xr[q].load(st.resid + m * D, D, lane);
+      if (st.skip) sk[q].load(st.skip + m * D, D, lane);
+    }
+    R8 lww, lbb, l2ww, l2bb;
+    if (st.lw) lww.load(st.lw, D, lane), lbb.load(st.lb, D, lane);
+    if (st.l2w) l2ww.load(st.l2w, D, lane), l2bb.load(st.l2b, D, lane);
+#pragma unroll
     for (int q = 0; q < RPW; ++q) {
       const int rl = RPW * wn + q;
       const int64_t m = (int64_t)row0 + rl;
       if (m >= row_end) continue;  // (wave-uniform)
-      R8 r, x;
+      R8 r;
+      const R8& x = xr[q];
       const f32x4 v0 = *(const f32x4*)(stg + rl * D + ((lane ^ (rl & 31)) << 2));
       const f32x4 v1 = *(const f32x4*)(stg + rl * D + (((64 + lane) ^ (rl & 31)) << 2));
-      x.load(st.resid + m * D, D, lane);
       r.e[0] = v0[0] + x.e[0], r.e[1] = v0[1] + x.e[1], r.e[2] = v0[2] + x.e[2], r.e[3] = v0[3] + x.e[3];
       r.e[4] = v1[0] + x.e[4], r.e[5] = v1[1] + x.e[5], r.e[6] = v1[2] + x.e[6], r.e[7] = v1[3] + x.e[7];
-      r.store(st.out + m * D, D, lane);
-      if (st.ln16) {
+      if (st.skip) {  // the block's tail: LN(skip + skip_scale * r) out, LN of that for the next block
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.e[j] = sk[q].e[j] + st.skip_scale * r.e[j];
         r.layernorm(lww, lbb, D, lane);
-        r.template store_h16<FMT>(st.ln16 + m * D, D, lane);
+        r.store(st.out + m * D, D, lane);
+        if (st.l2w) {
+          r.layernorm(l2ww, l2bb, D, lane);
+          r.template store_h16<FMT>(st.ln16 + m * D, D, lane);
+        }
+      } else {
+        r.store(st.out + m * D, D, lane);
+        if (st.ln16) {
+          r.layernorm(lww, lbb, D, lane);
+          r.template store_h16<FMT>(st.ln16 + m * D, D, lane);
+        }
       }
     }
   }
@@ -366,14 +387,17 @@ __device__ __forceinline__ void pair_tail(const PairTail& st, f32x4 (&y)[RT][4],
 // 2 no weight refills, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores; 7 = the real kernel with the erf-form GELU
 // of the LDS-staged kernel; 8 = GELU pieces interleaved with the phase-2 MFMAs of the same wave; 9 = stamped build
 template <typename HT, int RT, int NJ, int DIN, int KO>
-__global__ __launch_bounds__(NT, (RT <= 2 ? 4 : 2)) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h, const PairTail st) {
+__global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h, const PairTail st) {
   typedef typename HT::frag_t frag_t;
   constexpr bool TAIL = KO == 10;  // the Performer tail (post-norm, stylization, out_layers.2, residual) behind the pair
   static_assert(!TAIL || (NJ == 4 && DIN == 512 && RT <= 4), "the tail is written for D = 512 rows");
   typedef XGeo<RT, DIN, NJ, TAIL> G;
   constexpr int NKO = DIN / 128, NLINE = DIN / 64;
   constexpr int NA = 4, PD = NA - 1;  // A-fragment ring: NA registers, PD fragments ahead of the MFMAs
-  constexpr int NR = (RT == 4 && NJ == 4 && DIN % 256 == 0) ? 16 : 8;  // weight ring: fragments in flight per wave (16 where the accumulators leave room)
+  // weight ring: fragments in flight per wave, 16 where the accumulators leave room.  The 32-row form runs one workgroup per CU
+  // like the others (its launches have at most one tile per CU: <= 8192 rows), so it takes the 256-register budget and the deep
+  // ring as well: what bounds these short-tile launches is how many weight bytes a CU has in flight
+  constexpr int NR = (RT <= 4 && NJ == 4 && DIN % 256 == 0) ? 16 : 8;
   constexpr int NF = 4 * RT;          // A fragments per unrolled body (4 K steps x RT row tiles)
   constexpr bool ILV = KO == 8;  // knob 48: GELU pieces interleaved with phase-2 MFMAs (measured 1.5 % SLOWER than back to back)
   static_assert(NF % NA == 0, "the ring must close over the unrolled body");
@@ -771,8 +795,8 @@ static int launch_stream(const MdmMlpDesc& a, int th, hipStream_t stream, const 
     attr = true;
   }
   const int tiles = (int)(a.M / th) + (a.goff ? a.ngroups : 1);  // upper bound of the tile count
-  // persistent: the resident workgroups (one per CU; two of the 32-row form: 128 registers, 40 KiB of LDS) walk the tiles
-  const int res = device_cus() * (RT <= 2 ? 2 : 1);
+  // persistent: the resident workgroups (one per CU) walk the tiles
+  const int res = device_cus();
   const int grid = tiles < res ? tiles : res;
   if (a.h16 == MDM_H16_F16) {
     hipLaunchKernelGGL((fused_mlp_stream_kernel<HF, RT, NJ, DIN, KO>), dim3(grid), dim3(NT), smem, stream, a, th, tail);
@@ -828,7 +852,7 @@ bool fused_pair_style_supported(const MdmMlpDesc& a) {
 int fused_pair_style(const MdmMlpDesc& a, const PairTail& t, hipStream_t stream) {
   if (!a.X || !fused_pair_style_supported(a)) return MDM_ERR_UNSUPPORTED;
   if (!t.pw || !t.pb || !t.sw || !t.sb || !t.sc || t.S <= 0 || !t.ws || !t.bias || !t.resid || !t.out || (t.ln16 && (!t.lw || !t.lb)) ||
-      ((uintptr_t)t.ws & 15))
+      ((uintptr_t)t.ws & 15) || (t.skip && (!t.lw || !t.lb)) || (t.l2w && (!t.l2b || !t.ln16 || !t.skip)))
     return MDM_ERR_ARG;
   const int th = mlp_stream_tile_h(a.M, 4);  // the tail stages fp32 rows: 64-row tiles at most
   if (th <= 32) return launch_stream<2, 512, 10>(a, th, stream, t);

@@ -196,10 +196,39 @@ int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float*
 }
 
 // PerformerSelfAttention (fast_attention.py:137-179): xn = pre_norm(x) already computed; out = x + 0.1*style(...)
-// next_w / next_b / next16 / next_done: optional LayerNorm of `out` for the block that follows, written as 16-bit rows by the
-// fused tail when it runs (*next_done says whether it did)
+// What the fused tail (csrc/mlp_stream.hip pair_tail) may do beyond the Performer itself when it runs (*done says whether it did):
+//   skip == NULL: ln16 = LN(out; lw, lb)                          (the pre-norm of the block that follows)
+//   skip != NULL: out  = LN(skip + skip_scale * r; lw, lb) with r the Performer's own output, which is not written;
+//                 ln16 = LN(out; l2w, l2b) when l2w is set         (the tail of DualSelfAttentionBlock, fast_attention.py:219-225)
+struct PerfTail {
+  const float *lw = nullptr, *lb = nullptr;
+  uint16_t* ln16 = nullptr;
+  const float* skip = nullptr;
+  float skip_scale = 0.f;
+  const float *l2w = nullptr, *l2b = nullptr;
+  bool* done = nullptr;
+};
+
+// the proj_out pair (fast_attention.py:121-126) as one launch of the streamed-weight kernel, in place on t4
+MdmMlpDesc proj_pair_desc(const Ctx& c, const MdmPerformer& p) {
+  const int D = c.m->D;
+  MdmMlpDesc f = {};
+  f.X = (const uint16_t*)c.w.t4, f.ldx = D, f.M = (int)c.M, f.Din = D, f.F = D, f.Dout = D;
+  f.b1 = p.proj0_b, f.b2 = p.proj3_b, f.wstream = p.proj_ws, f.wstream_gs = 2 * (int64_t)D * D;
+  f.r1_scale = 1.f, f.C16 = (uint16_t*)c.w.t4, f.ldc = D, f.h16 = c.h16;  // in place: a tile's rows are in LDS before its stores
+  return f;
+}
+// whether performer() runs that pair (knob 32: two GEMMs) / the pair AND the Performer's tail (knob 35: the tail as its own launches)
+bool proj_pair_fused(const Ctx& c, const MdmPerformer& p) {
+  return c.bf && g_bf16_variant != 25 && p.proj_ws && g_bf16_variant != 32;
+}
+bool performer_tail_fused(const Ctx& c, const MdmPerformer& p) {
+  return proj_pair_fused(c, p) && p.style.out_ws && g_bf16_variant != 35 && g_bf16_variant != 30 &&
+         fused_pair_style_supported(proj_pair_desc(c, p));
+}
+
 int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const float* sc, float* out,
-              const float* next_w = nullptr, const float* next_b = nullptr, uint16_t* next16 = nullptr, bool* next_done = nullptr) {
+              const PerfTail& pt = PerfTail()) {
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H, mf = dh;  // m = min(dh, 256) = dh for dh <= 256
   const Work& w = c.w;
@@ -266,20 +295,17 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
   // proj_out: Linear -> GELU -> Linear                             (:121-126,165)
   const bool t16 = c.bf && g_bf16_variant != 25;  // the projection's output feeds a LayerNorm only: bf16 in throughput mode
   bool pair = false;
-  if (t16 && p.proj_ws && g_bf16_variant != 32) {  // one launch, hidden layer on chip (csrc/mlp_stream.hip); knob 32: two GEMMs
-    MdmMlpDesc f = {};
-    f.X = (const uint16_t*)w.t4, f.ldx = D, f.M = (int)c.M, f.Din = D, f.F = D, f.Dout = D;
-    f.b1 = p.proj0_b, f.b2 = p.proj3_b, f.wstream = p.proj_ws, f.wstream_gs = 2 * (int64_t)D * D;
-    f.r1_scale = 1.f, f.C16 = (uint16_t*)w.t4, f.ldc = D, f.h16 = c.h16;  // in place: a tile's rows are in LDS before its stores
+  if (proj_pair_fused(c, p)) {  // one launch, hidden layer on chip (csrc/mlp_stream.hip)
+    const MdmMlpDesc f = proj_pair_desc(c, p);
     // ... and the tail (post_norm, stylization, out_layers.2, residual, the next block's LayerNorm) in the same launch: the
     // pair's rows never leave the CU (knob 35: the tail as its own launch)
-    if (p.style.out_ws && g_bf16_variant != 35 && g_bf16_variant != 30 && fused_pair_style_supported(f)) {
+    if (performer_tail_fused(c, p)) {
       PairTail t = {};
       t.pw = p.post_w, t.pb = p.post_b, t.sw = p.style.norm_w, t.sb = p.style.norm_b, t.sc = sc, t.S = c.S;
       t.ws = p.style.out_ws, t.bias = p.style.out_b, t.resid = x, t.out_scale = 0.1f, t.out = out;
-      if (next16) t.lw = next_w, t.lb = next_b, t.ln16 = next16;
+      t.lw = pt.lw, t.lb = pt.lb, t.ln16 = pt.ln16, t.skip = pt.skip, t.skip_scale = pt.skip_scale, t.l2w = pt.l2w, t.l2b = pt.l2b;
       MDM_TRY(fused_pair_style(f, t, c.s));
-      if (next_done) *next_done = next16 != nullptr;
+      if (pt.done) *pt.done = true;
       return MDM_OK;
     }
     if (fused_mlp_stream_supported(f)) {
@@ -305,12 +331,35 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
   const int D = c.m->D;
   const Work& w = c.w;
   const int64_t scs = (int64_t)c.B * 2 * D;
+  // With the Performers' tails fused into their projection launches (16-bit modes, D = 512) the block's own tail goes there too:
+  // skip = GELU(Lin(x)) is computed FIRST (into the FFN's hidden buffer, free during this block), and the second Performer's
+  // launch ends with out = post_norm(skip + 0.1 * global_out) and the next block's pre-norm -- no D x D GEMM waiting behind the
+  // attention chain, no LayerNorm launch behind that.
+  const bool tails = performer_tail_fused(c, l.local) && performer_tail_fused(c, l.global);
+  float* const skipbuf = w.f1;
+  if (tails) {
+    LinOpts o;
+    o.act = ACT_GELU;
+    MDM_TRY(linear(c, act_bf16(x16), c.M, D, l.skip, l.skip_b, D, skipbuf, nullptr, o));
+  }
   // h = pre_norm(x) -> t1 ; local.pre_norm(h) -> t3
   MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, 0, l.local.pre_w, l.local.pre_b, w.t3, fmt16(c), c.s));
   bool normed = false;  // local_out -> t5; the fused tail also leaves global.pre_norm(local_out) in t3 (t3 is dead by then)
-  MDM_TRY(performer(c, l.local, w.t1, act_of(c, w.t3), sc4 + 0 * scs, w.t5, l.global.pre_w, l.global.pre_b,
-                    c.bf ? (uint16_t*)w.t3 : nullptr, &normed));
+  {
+    PerfTail pt;
+    if (c.bf) pt.lw = l.global.pre_w, pt.lb = l.global.pre_b, pt.ln16 = (uint16_t*)w.t3, pt.done = &normed;
+    MDM_TRY(performer(c, l.local, w.t1, act_of(c, w.t3), sc4 + 0 * scs, w.t5, pt));
+  }
   if (!normed) MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
+  if (tails && normed) {
+    bool done = false;
+    PerfTail pt;
+    pt.skip = skipbuf, pt.skip_scale = 0.1f, pt.lw = l.dual_post_w, pt.lb = l.dual_post_b, pt.done = &done;
+    if (next_w) pt.l2w = next_w, pt.l2b = next_b, pt.ln16 = (uint16_t*)w.t2;
+    MDM_TRY(performer(c, l.global, w.t5, act_of(c, w.t3), sc4 + 1 * scs, out, pt));
+    if (done) return MDM_OK;
+    return MDM_ERR_LAUNCH;  // (unreachable: performer_tail_fused said the tail runs)
+  }
   MDM_TRY(performer(c, l.global, w.t5, act_of(c, w.t3), sc4 + 1 * scs, w.t1));  // global_out -> t1
   // skip = GELU(Lin(x)); out = post_norm(skip + 0.1 * global)      (:219-225)
   {
