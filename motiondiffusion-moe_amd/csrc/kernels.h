@@ -41,6 +41,10 @@ int den_ln(const float* num, const float* phi, int64_t M, int H, int dh, const f
 int head_softmax(float* q, int64_t units, int dh, hipStream_t s);
 // fused Performer attention core (perf_attn.hip): qkv fp32 (M,3D) -> LN_dh(num/den) as bf16 (M,D)
 bool perf_attn_supported(int dh, int S);
+bool perf_attn_qkv_supported(int dh, int S, int H);
+int perf_attn_qkv(const uint16_t* xn, const uint16_t* wqkv, int ldw, const float* bias, float alpha, uint16_t* qscratch, int h16,
+                  const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B, int S, int H, int dh,
+                  uint16_t* out, hipStream_t s);
 int perf_attn(const void* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s);
 // perf_attn2.hip: the same core at head_dim 256 (big model) in two launches (feature maps; KV state + num + LN); scratch:

@@ -235,13 +235,20 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
   const bool fused256 = c.bf && g_bf16_variant != 23 && perf_attn256_supported(dh, c.S) &&
                         perf_attn256_scratch_bytes(c.B, H, c.S) <= c.M * 2 * D * (int64_t)sizeof(float);
   const bool fused = fused256 || (c.bf && perf_attn_supported(dh, c.S));
+  // head_dim 128, 16-bit modes: the q | k | v projection inside the attention core's launch (csrc/perf_attn.hip phase 0: one
+  // workgroup per (batch, head) multiplies its sample's rows with its head's 384 weight rows; k and v never leave the CU).
+  // Knob 50: the projection as its own GEMM launch.
+  const bool qkv_in = fused && !fused256 && xn.bf && g_bf16_variant != 50 && perf_attn_qkv_supported(dh, c.S, H);
   // q|k|v = 0.1 * (xn W^T + b)                                   (:145-157); bf16 when the fused attention core reads it
-  {
+  if (!qkv_in) {
     LinOpts o;
     o.alpha = 0.1f;
     MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, fused ? nullptr : w.qkv, fused ? (uint16_t*)w.qkv : nullptr, o));
   }
-  if (fused256) {
+  if (qkv_in) {
+    MDM_TRY(perf_attn_qkv((const uint16_t*)xn.p, p.qkv.hi, (int)p.qkv.ld, p.qkv_b, 0.1f, (uint16_t*)w.qkv, c.h16, p.feat.hi,
+                          (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, (uint16_t*)w.t4, c.s));
+  } else if (fused256) {
     // the same at head_dim 256 (big model) in two launches: feature maps (P^T resident), then KV state + num + LN per
     // (batch, head); qphi / kphi^T / den pass through w.phi (L2 / MALL resident)
     MDM_TRY(perf_attn256(w.qkv, c.h16, p.feat.hi, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, (uint16_t*)w.t4, w.phi, c.s));

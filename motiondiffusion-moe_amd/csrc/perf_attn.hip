@@ -40,13 +40,54 @@ __device__ __forceinline__ float quad_sum(float v) {  // across the 4 lanes that
   return v;
 }
 
-template <typename HT>
-__global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ PT,
+// QKV = true: the launch also computes its (batch, head)'s q | k | v rows, 0.1 * (xn W^T + b) (fast_attention.py:145-157), instead of
+// reading them: phase 0 below.  xn = the pre-normed 16-bit rows [B S, D]; wqkv = the 16-bit plane of query|key|value stacked [3 D][ldw];
+// the q rows pass through `qkv` (the q third of the [B S, 3 D] buffer, written and re-read by the same lanes), k and v never leave the CU.
+struct PerfQkv {
+  const uint16_t* xn;
+  const uint16_t* w;
+  int ldw;
+  const float* bias;  // [3 D]
+  float alpha;
+};
+
+// phase-0 staging of one K slice (64 columns) of the xn rows and of the head's q | k | v weight rows: global -> registers -> LDS.
+// Free functions on purpose: an array captured by a lambda keeps its stack slot (scratch memory).  Branch-free loads: chunk ids
+// past the end re-read the last chunk and are not landed.
+template <int NCH>
+__device__ __forceinline__ void qkv_fetch(u32x4 (&st)[NCH], int tid, int nch, int R, int S, int D, int h, int kk,
+                                          const uint16_t* __restrict__ xrow0, const PerfQkv& qa) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int id = tid + NTH * i;
+    id = id < nch ? id : nch - 1;
+    int row = id >> 3;
+    row = row < S ? row : S - 1;
+    const int wr = (id - R * 8) >> 3, g = wr >> 7;  // row of the W slice: q | k | v group g, row wr & 127 of head h
+    const uint16_t* src = id < R * 8 ? xrow0 + (int64_t)row * D : qa.w + (int64_t)(g * D + h * DH + (wr & 127)) * qa.ldw;
+    st[i] = *(const u32x4*)(src + kk * 64 + (id & 7) * 8);
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void qkv_land(const u32x4 (&st)[NCH], int tid, int nch, int R, uint8_t* stage) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = tid + NTH * i;
+    if (id < nch) {
+      const int row = id < R * 8 ? (id >> 3) : ((id - R * 8) >> 3);
+      uint8_t* base = id < R * 8 ? stage : stage + R * 128;
+      *(u32x4*)(base + row * 128 + ((((id & 7)) ^ (row & 7)) << 4)) = st[i];
+    }
+  }
+}
+
+template <typename HT, bool QKV>
+__global__ __launch_bounds__(NTH) void perf_attn_kernel(uint16_t* __restrict__ qkv, const uint16_t* __restrict__ PT,
                                                            int ldp, const float* __restrict__ hn_w,
                                                            const float* __restrict__ hn_b, const int* __restrict__ len,
-                                                           int S, int H, uint16_t* __restrict__ out) {
+                                                           int S, int H, uint16_t* __restrict__ out, const PerfQkv qa) {
   typedef typename HT::frag_t frag_t;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  extern __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[];
   uint16_t* smem = (uint16_t*)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -59,19 +100,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
   uint16_t* PTl = vT + vreg;  // P^T stays resident: the q features need it again (a second load from L2 sat between two
   uint16_t* KV = vT;          // barriers in the middle of the kernel)
   const int nvalid = min(len[b], S);
-
-  // LayerNorm gain/bias at this lane's input positions k = 32*ks + 8*q + j
   float gw[32], gb[32];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const f32x4 a = *(const f32x4*)(hn_w + 32 * ks + 8 * q), c = *(const f32x4*)(hn_w + 32 * ks + 8 * q + 4);
-    const f32x4 d = *(const f32x4*)(hn_b + 32 * ks + 8 * q), e = *(const f32x4*)(hn_b + 32 * ks + 8 * q + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      gw[8 * ks + j] = a[j], gw[8 * ks + 4 + j] = c[j];
-      gb[8 * ks + j] = d[j], gb[8 * ks + 4 + j] = e[j];
-    }
-  }
 
   // 128 x 128 16-bit = 2048 16-B chunks, 4 per thread: all loads in flight, then the LDS writes (named registers: an array
   // captured by a lambda keeps its stack slot, and a kernel with a private segment pays for it at every wave launch)
@@ -129,14 +158,106 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
     }
   };
   uint4 kq[MAXT][4], vr[MAXT][4];
+  if constexpr (QKV) {
+    // ---- phase 0: [S x 384] = xn[b] [S x 512] . (Wq_h | Wk_h | Wv_h)^T, K in 8 slices of 64 through two LDS stages ----------------
+    // stage = xn slice [R][64] (128-B rows) + W slice [384][64]; 16-B chunk c of a row r at slot c ^ (r & 7).  Waves split the 24
+    // column tiles (3 each: 48 of the 384 columns), every wave multiplies all row tiles: 39 accumulators at 13 row tiles.
+    constexpr int MT = 13;                    // row tiles the fused form holds (S <= 208: the [R][384] image must fit the LDS)
+    const int R = SP;
+    const int ABYTES = R * 128, STAGE = ABYTES + 384 * 128;
+    constexpr int NCH = (MT * 16 * 8 + 384 * 8 + NTH - 1) / NTH;  // 16-B chunks per thread and stage (10)
+    const int nch = R * 8 + 384 * 8;
+    u32x4 st[NCH];
+    const int kk0 = 0;
+    const uint16_t* xrow0 = qa.xn + (int64_t)b * S * D;
+    f32x4 acc[MT][3];
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    const int tile = wid + NW * i;
-    if (tile < ntile) {
-      raw_load(1, tile, kq[i]);
-      raw_load(2, tile, vr[i]);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    qkv_fetch<NCH>(st, tid, nch, R, S, D, h, kk0, xrow0, qa);
+#pragma unroll 1
+    for (int kk = 0; kk < 8; ++kk) {
+      uint8_t* stage = smem_raw + (kk & 1) * STAGE;
+      int to = tid;  // opaque per slice: hoisted out of this loop the staging addresses (3 registers per chunk) would be spilled
+      asm volatile("" : "+v"(to));
+      qkv_land<NCH>(st, to, nch, R, stage);
+      __syncthreads();
+      if (kk + 1 < 8) qkv_fetch<NCH>(st, to, nch, R, S, D, h, kk + 1, xrow0, qa);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int sl = (((k2 * 4 + q) ^ (r16 & 7)) << 4);
+        frag_t wf[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wf[j] = *(const frag_t*)(stage + ABYTES + (16 * (3 * wid + j) + r16) * 128 + sl);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (mt < ntile) {
+            const frag_t xf = *(const frag_t*)(stage + (16 * mt + r16) * 128 + sl);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[mt][j] = HT::mfma16(wf[j], xf, acc[mt][j]);  // lane: row 16 mt + r16, cols 16 ct + 4 q ..
+          }
+        }
+      }
+    }
+    __syncthreads();  // the stages are dead: their LDS takes the q | k | v rows
+    // rows as 16-bit [R][384] (768-B rows; 16-B chunk c at slot c ^ (row & 15), inside its group of 16 chunks)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = 16 * (3 * wid + j) + 4 * q, g = col >> 7;  // column in q | k | v, its group
+      const f32x4 bb = *(const f32x4*)(qa.bias + g * D + h * DH + (col & 127));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt < ntile) {
+          const int row = 16 * mt + r16;
+          const f32x4 v = acc[mt][j];
+          *(uint2*)(smem_raw + row * 768 + ((((col >> 3)) ^ (row & 15)) << 4) + ((col >> 2) & 1) * 8) =
+              make_uint2(HT::pack(qa.alpha * (v[0] + bb[0]), qa.alpha * (v[1] + bb[1])),
+                         HT::pack(qa.alpha * (v[2] + bb[2]), qa.alpha * (v[3] + bb[3])));
+        }
+      }
+    }
+    __syncthreads();
+    // every wave takes the k and v rows of its own tiles (the register layout of raw_load) and hands its q rows to memory
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int tile = wid + NW * i;
+      if (tile < ntile) {
+        const int row = tile * 16 + r16;
+        const uint8_t* ir = smem_raw + row * 768;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          kq[i][ks] = *(const uint4*)(ir + (((16 + 4 * ks + q) ^ (row & 15)) << 4));
+          vr[i][ks] = *(const uint4*)(ir + (((32 + 4 * ks + q) ^ (row & 15)) << 4));
+          const uint4 qv = *(const uint4*)(ir + (((4 * ks + q) ^ (row & 15)) << 4));
+          if (row < S) *(uint4*)(qkv + ((int64_t)(b * S + row)) * 3 * D + h * DH + 32 * ks + 8 * q) = qv;
+        }
+      }
+    }
+    __syncthreads();  // the image is dead: P^T and the feature images land in the same LDS
+  } else {
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int tile = wid + NW * i;
+      if (tile < ntile) {
+        raw_load(1, tile, kq[i]);
+        raw_load(2, tile, vr[i]);
+      }
     }
   }
+
+  // LayerNorm gain/bias at this lane's input positions k = 32*ks + 8*q + j (loaded behind phase 0, which needs the registers)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const f32x4 a = *(const f32x4*)(hn_w + 32 * ks + 8 * q), c = *(const f32x4*)(hn_w + 32 * ks + 8 * q + 4);
+    const f32x4 d = *(const f32x4*)(hn_b + 32 * ks + 8 * q), e = *(const f32x4*)(hn_b + 32 * ks + 8 * q + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gw[8 * ks + j] = a[j], gw[8 * ks + 4 + j] = c[j];
+      gb[8 * ks + j] = d[j], gb[8 * ks + 4 + j] = e[j];
+    }
+  }
+
 
   load_PT();
   __syncthreads();
@@ -320,29 +441,57 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(const uint16_t* __restri
 }  // namespace
 
 bool perf_attn_supported(int dh, int S) { return dh == DH && S >= 1 && S <= 224; }
+// the form that computes q | k | v itself holds 13 row tiles (its [R][384] row image must fit the 160 KiB of LDS) and D = 512
+bool perf_attn_qkv_supported(int dh, int S, int H) { return dh == DH && H == 4 && S >= 1 && S <= 208; }
+
+namespace {
+template <bool QKV>
+int launch_perf_attn(uint16_t* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
+                     int S, int H, uint16_t* out, const PerfQkv& qa, hipStream_t s) {
+  const int TP = (S + 31) & ~31, TS = TP + 8, SP = (S + 15) & ~15;
+  const int vreg = (TP * DH > MF * PS) ? TP * DH : MF * PS;
+  int smem = (MF * TS + vreg + DH * PS) * 2;
+  if (QKV) {
+    const int stages = 2 * (SP * 128 + 384 * 128), img = SP * 768;
+    smem = smem > stages ? smem : stages;
+    smem = smem > img ? smem : img;
+  }
+  static DevInt attr;
+  if (smem > attr) {
+    if (hipFuncSetAttribute((const void*)perf_attn_kernel<HB, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)perf_attn_kernel<HF, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return MDM_ERR_LAUNCH;
+    attr = smem;
+  }
+  if (h16 == MDM_H16_F16) {
+    hipLaunchKernelGGL((perf_attn_kernel<HF, QKV>), dim3(B * H), dim3(NTH), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out, qa);
+  } else {
+    hipLaunchKernelGGL((perf_attn_kernel<HB, QKV>), dim3(B * H), dim3(NTH), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out, qa);
+  }
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+}  // namespace
 
 // h16: format (MDM_H16_*) of the qkv rows, of the feature matrix P^T and of the output rows
 int perf_attn(const void* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
               int S, int H, int dh, uint16_t* out, hipStream_t s) {
   if (!perf_attn_supported(dh, S) || (h16 != MDM_H16_BF16 && h16 != MDM_H16_F16)) return MDM_ERR_UNSUPPORTED;
   if (!qkv || !PT || !hn_w || !hn_b || !len || !out || (ldp & 7)) return MDM_ERR_ARG;
-  const int TP = (S + 31) & ~31, TS = TP + 8;
-  const int vreg = (TP * DH > MF * PS) ? TP * DH : MF * PS;
-  const int smem = (MF * TS + vreg + DH * PS) * 2;
-  static DevInt attr;
-  if (smem > attr) {
-    if (hipFuncSetAttribute((const void*)perf_attn_kernel<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-        hipFuncSetAttribute((const void*)perf_attn_kernel<HF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-      return MDM_ERR_LAUNCH;
-    attr = smem;
-  }
-  if (h16 == MDM_H16_F16) {
-    hipLaunchKernelGGL(perf_attn_kernel<HF>, dim3(B * H), dim3(NTH), smem, s, (const uint16_t*)qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
-  } else {
-    hipLaunchKernelGGL(perf_attn_kernel<HB>, dim3(B * H), dim3(NTH), smem, s, (const uint16_t*)qkv, PT, ldp, hn_w, hn_b, len, S, H, out);
-  }
-  MDM_RETURN_IF_LAUNCH_FAILED();
-  return MDM_OK;
+  return launch_perf_attn<false>((uint16_t*)qkv, h16, PT, ldp, hn_w, hn_b, len, B, S, H, out, PerfQkv(), s);
+}
+
+// the same with the q | k | v projection inside: xn 16-bit [B S, D] (format h16), wqkv the 16-bit plane [3 D][ldw] of the stacked
+// query | key | value weights, bias [3 D], q | k | v = alpha * (xn W^T + b); qscratch = a [B S, 3 D] 16-bit buffer (its q third is used)
+int perf_attn_qkv(const uint16_t* xn, const uint16_t* wqkv, int ldw, const float* bias, float alpha, uint16_t* qscratch, int h16,
+                  const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B, int S, int H, int dh,
+                  uint16_t* out, hipStream_t s) {
+  if (!perf_attn_qkv_supported(dh, S, H) || (h16 != MDM_H16_BF16 && h16 != MDM_H16_F16)) return MDM_ERR_UNSUPPORTED;
+  if (!xn || !wqkv || !bias || !qscratch || !PT || !hn_w || !hn_b || !len || !out || (ldp & 7) || (ldw & 7) ||
+      ((((uintptr_t)xn) | ((uintptr_t)wqkv) | ((uintptr_t)qscratch)) & 15))
+    return MDM_ERR_ARG;
+  const PerfQkv qa = {xn, wqkv, ldw, bias, alpha};
+  return launch_perf_attn<true>(qscratch, h16, PT, ldp, hn_w, hn_b, len, B, S, H, out, qa, s);
 }
 
 }  // namespace mdm

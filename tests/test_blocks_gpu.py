@@ -215,6 +215,30 @@ def test_performer_tail_fused_into_the_projection_pair(B, S, precision):
     assert e_f < TOL[precision] and e_s < TOL[precision]
 
 
+@pytest.mark.parametrize("precision", [2, 1])
+@pytest.mark.parametrize("B,S", [(2, 98), (3, 37), (1, 5), (2, 196), (4, 208)])
+def test_qkv_projection_inside_the_attention_core(B, S, precision):
+    """16-bit modes, head_dim 128: the Performer's query | key | value projection runs inside the attention core's launch
+    (csrc/perf_attn.hip phase 0); knob 50 runs it as its own GEMM launch.  Same products, same 16-bit rounding of q | k | v:
+    the block outputs agree to accumulation-order rounding, and both agree with the oracle; ragged lengths, S not a multiple
+    of 16, and the largest S the fused form takes (208)."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, 6, precision)
+    L = pkg("_lib")
+    fused = _run_block(m, L.BLOCK_DUAL, h, sc, length, xf)
+    L.lib().mdm_set_gemm_variant(50)
+    try:
+        split = _run_block(m, L.BLOCK_DUAL, h, sc, length, xf)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    with torch.no_grad():
+        ref = R.dual_self_attention(h, emb, R.src_mask(S, length), sd, pre + ".dual_self_attn", H, eph, proj, "low.0")
+    d, e_f, e_s = rel_inf(fused, split), rel_inf(fused, ref), rel_inf(split, ref)
+    print(f"B={B} S={S} precision {precision}: qkv inside vs own launch {d:.2e}; vs oracle {e_f:.2e} / {e_s:.2e}")
+    assert torch.isfinite(fused).all()
+    assert d < (1e-3 if precision == 2 else 8e-3)
+    assert e_f < TOL[precision] and e_s < TOL[precision]
+
+
 @pytest.mark.parametrize("precision", [3, 1, 2, 4])
 def test_named_block_entry_points(precision):
     """The per-block C entry points named in SURVEY.md §8(b): the aliases must reproduce mdm_block_forward bit for bit, and
