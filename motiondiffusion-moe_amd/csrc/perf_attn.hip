@@ -51,42 +51,83 @@ struct PerfQkv {
   float alpha;
 };
 
-// phase-0 staging of one K slice (64 columns) of the xn rows and of the head's q | k | v weight rows: global -> registers -> LDS.
-// Free functions on purpose: an array captured by a lambda keeps its stack slot (scratch memory).  Branch-free loads: chunk ids
-// past the end re-read the last chunk and are not landed.
+// phase-0 staging of one K slice (64 columns) of the sample's xn rows: global -> registers -> LDS (free functions on purpose: an
+// array captured by a lambda keeps its stack slot = scratch memory).  Branch-free loads: chunk ids past the end re-read the last
+// chunk and are not landed.  16-B chunk c of row r at slot c ^ ((r >> 1) & 7): two 128-B rows span the 64 banks, so the 16 rows of
+// a fragment read are conflict-free when the 8 rows of either parity take 8 different slots.
 template <int NCH>
-__device__ __forceinline__ void qkv_fetch(u32x4 (&st)[NCH], int tid, int nch, int R, int S, int D, int h, int kk,
-                                          const uint16_t* __restrict__ xrow0, const PerfQkv& qa) {
+__device__ __forceinline__ void qkv_fetch(u32x4 (&st)[NCH], int tid, int R, int S, int D, int kk, const uint16_t* __restrict__ xrow0) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int id = tid + NTH * i;
-    id = id < nch ? id : nch - 1;
+    id = id < R * 8 ? id : R * 8 - 1;
     int row = id >> 3;
     row = row < S ? row : S - 1;
-    const int wr = (id - R * 8) >> 3, g = wr >> 7;  // row of the W slice: q | k | v group g, row wr & 127 of head h
-    const uint16_t* src = id < R * 8 ? xrow0 + (int64_t)row * D : qa.w + (int64_t)(g * D + h * DH + (wr & 127)) * qa.ldw;
-    st[i] = *(const u32x4*)(src + kk * 64 + (id & 7) * 8);
+    st[i] = *(const u32x4*)(xrow0 + (int64_t)row * D + kk * 64 + (id & 7) * 8);
   }
 }
 template <int NCH>
-__device__ __forceinline__ void qkv_land(const u32x4 (&st)[NCH], int tid, int nch, int R, uint8_t* stage) {
+__device__ __forceinline__ void qkv_land(const u32x4 (&st)[NCH], int tid, int R, uint8_t* stage) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int id = tid + NTH * i;
-    if (id < nch) {
-      const int row = id < R * 8 ? (id >> 3) : ((id - R * 8) >> 3);
-      uint8_t* base = id < R * 8 ? stage : stage + R * 128;
-      *(u32x4*)(base + row * 128 + ((((id & 7)) ^ (row & 7)) << 4)) = st[i];
+    if (id < R * 8) {
+      const int row = id >> 3;
+      *(u32x4*)(stage + row * 128 + ((((id & 7)) ^ ((row >> 1) & 7)) << 4)) = st[i];
     }
   }
 }
 
-template <typename HT, bool QKV>
+// Row tiles the fused form holds: 13 (S <= 208: the [R][384] row image must fit the LDS) or 7 (S <= 112, the coarse scale).  The
+// count is a template argument: with a run-time bound every row tile is its own basic block and its fragment read is waited for
+// right in front of its three MFMAs.
+template <int MT>
+struct QkvGeo {
+  static constexpr int R = MT * 16;                       // rows staged and multiplied (rows >= S: copies of the last row)
+  static constexpr int NCH = (R * 8 + NTH - 1) / NTH;     // 16-B chunks per thread and K slice
+};
+
+// one K slice (two K steps of 32): land its rows in `stage`, barrier, request the next slice into the same registers, MFMAs.
+// wr: the wave's weight ring, 3 fragments per K step x 2 steps; a slot is refilled with the fragment two steps ahead right after use.
+// The row fragments go through two registers, one read ahead of the MFMAs, pinned per row tile.
+template <typename HT, int MT, bool PIN = true>
+__device__ __forceinline__ void qkv_slice(int kk, u32x4 (&st)[QkvGeo<MT>::NCH], f32x4 (&acc)[MT][3], typename HT::frag_t (&wr)[6],
+                                          const uint16_t* const (&wrow)[3], uint8_t* stage, int tid, int r16, int q, int S, int D,
+                                          const uint16_t* __restrict__ xrow0) {
+  typedef typename HT::frag_t frag_t;
+  constexpr int R = QkvGeo<MT>::R, NCH = QkvGeo<MT>::NCH;
+  int to = tid;  // opaque per slice: hoisted out of the K loop the staging addresses would be spilled
+  asm volatile("" : "+v"(to));
+  qkv_land<NCH>(st, to, R, stage);
+  __syncthreads();
+  if (kk + 1 < 8) qkv_fetch<NCH>(st, to, R, S, D, kk + 1, xrow0);
+  const uint8_t* xb = stage + r16 * 128;
+  frag_t xf[2];
+  xf[0] = *(const frag_t*)(xb + (((q) ^ ((r16 >> 1) & 7)) << 4));
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int n = k2 * MT + mt + 1;  // the fragment after this one: (step n / MT, row tile n % MT)
+      if (n < 2 * MT) xf[n & 1] = *(const frag_t*)(xb + (n % MT) * 2048 + ((((n / MT) * 4 + q) ^ ((r16 >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[mt][j] = HT::mfma16(wr[3 * k2 + j], xf[(n - 1) & 1], acc[mt][j]);  // lane: row 16 mt + r16, cols 16 ct + 4 q ..
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
+    int nxt = 2 * kk + k2 + 2;  // the K step this slot holds next (past the end: re-read the last one, never used)
+    nxt = nxt < 16 ? nxt : 15;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wr[3 * k2 + j] = *(const frag_t*)(wrow[j] + 32 * nxt);
+  }
+}
+
+template <typename HT, int QMT>  // QMT: 0 = q | k | v rows read from memory; 7 / 13 = computed here for that many row tiles
 __global__ __launch_bounds__(NTH) void perf_attn_kernel(uint16_t* __restrict__ qkv, const uint16_t* __restrict__ PT,
                                                            int ldp, const float* __restrict__ hn_w,
                                                            const float* __restrict__ hn_b, const int* __restrict__ len,
                                                            int S, int H, uint16_t* __restrict__ out, const PerfQkv qa) {
   typedef typename HT::frag_t frag_t;
+  constexpr bool QKV = QMT > 0;
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem_raw[];
   uint16_t* smem = (uint16_t*)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
@@ -159,47 +200,31 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(uint16_t* __restrict__ q
   };
   uint4 kq[MAXT][4], vr[MAXT][4];
   if constexpr (QKV) {
-    // ---- phase 0: [S x 384] = xn[b] [S x 512] . (Wq_h | Wk_h | Wv_h)^T, K in 8 slices of 64 through two LDS stages ----------------
-    // stage = xn slice [R][64] (128-B rows) + W slice [384][64]; 16-B chunk c of a row r at slot c ^ (r & 7).  Waves split the 24
-    // column tiles (3 each: 48 of the 384 columns), every wave multiplies all row tiles: 39 accumulators at 13 row tiles.
-    constexpr int MT = 13;                    // row tiles the fused form holds (S <= 208: the [R][384] image must fit the LDS)
-    const int R = SP;
-    const int ABYTES = R * 128, STAGE = ABYTES + 384 * 128;
-    constexpr int NCH = (MT * 16 * 8 + 384 * 8 + NTH - 1) / NTH;  // 16-B chunks per thread and stage (10)
-    const int nch = R * 8 + 384 * 8;
-    u32x4 st[NCH];
-    const int kk0 = 0;
+    // ---- phase 0: [S x 384] = xn[b] [S x 512] . (Wq_h | Wk_h | Wv_h)^T -------------------------------------------------------------
+    // The rows are what the waves share: K slices of 64 columns go global -> registers -> LDS one slice ahead (two LDS stages; a
+    // second register set would not fit beside the 39 accumulators).  The weights are private to a wave (waves split the 24 column tiles, 3 each = 48 of the 384 columns, and
+    // multiply all row tiles: 39 accumulators at 13 row tiles): its 48 fragments stream global -> registers through a ring that
+    // runs two K steps ahead and never touch LDS.
+    constexpr int MT = QKV ? QMT : 1, NCH = QkvGeo<MT>::NCH, R = QkvGeo<MT>::R;
     const uint16_t* xrow0 = qa.xn + (int64_t)b * S * D;
+    const uint16_t* wrow[3];  // this lane's row of the wave's three weight fragments, at k = 8 q
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ct = 3 * wid + j, g = ct >> 3;
+      wrow[j] = qa.w + (int64_t)(g * D + h * DH + ((16 * ct) & 127) + r16) * qa.ldw + 8 * q;
+    }
+    frag_t wr[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) wr[f] = *(const frag_t*)(wrow[f % 3] + 32 * (f / 3));
     f32x4 acc[MT][3];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    qkv_fetch<NCH>(st, tid, nch, R, S, D, h, kk0, xrow0, qa);
+    u32x4 sa[NCH];
+    qkv_fetch<NCH>(sa, tid, R, S, D, 0, xrow0);
 #pragma unroll 1
-    for (int kk = 0; kk < 8; ++kk) {
-      uint8_t* stage = smem_raw + (kk & 1) * STAGE;
-      int to = tid;  // opaque per slice: hoisted out of this loop the staging addresses (3 registers per chunk) would be spilled
-      asm volatile("" : "+v"(to));
-      qkv_land<NCH>(st, to, nch, R, stage);
-      __syncthreads();
-      if (kk + 1 < 8) qkv_fetch<NCH>(st, to, nch, R, S, D, h, kk + 1, xrow0, qa);
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const int sl = (((k2 * 4 + q) ^ (r16 & 7)) << 4);
-        frag_t wf[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) wf[j] = *(const frag_t*)(stage + ABYTES + (16 * (3 * wid + j) + r16) * 128 + sl);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if (mt < ntile) {
-            const frag_t xf = *(const frag_t*)(stage + (16 * mt + r16) * 128 + sl);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[mt][j] = HT::mfma16(wf[j], xf, acc[mt][j]);  // lane: row 16 mt + r16, cols 16 ct + 4 q ..
-          }
-        }
-      }
-    }
+    for (int kk = 0; kk < 8; ++kk) qkv_slice<HT, MT>(kk, sa, acc, wr, wrow, smem_raw + (kk & 1) * (R * 128), tid, r16, q, S, D, xrow0);
     __syncthreads();  // the stages are dead: their LDS takes the q | k | v rows
     // rows as 16-bit [R][384] (768-B rows; 16-B chunk c at slot c ^ (row & 15), inside its group of 16 chunks)
 #pragma unroll
@@ -208,13 +233,11 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(uint16_t* __restrict__ q
       const f32x4 bb = *(const f32x4*)(qa.bias + g * D + h * DH + (col & 127));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        if (mt < ntile) {
-          const int row = 16 * mt + r16;
-          const f32x4 v = acc[mt][j];
-          *(uint2*)(smem_raw + row * 768 + ((((col >> 3)) ^ (row & 15)) << 4) + ((col >> 2) & 1) * 8) =
-              make_uint2(HT::pack(qa.alpha * (v[0] + bb[0]), qa.alpha * (v[1] + bb[1])),
-                         HT::pack(qa.alpha * (v[2] + bb[2]), qa.alpha * (v[3] + bb[3])));
-        }
+        const int row = 16 * mt + r16;
+        const f32x4 v = acc[mt][j];
+        *(uint2*)(smem_raw + row * 768 + ((((col >> 3)) ^ (row & 15)) << 4) + ((col >> 2) & 1) * 8) =
+            make_uint2(HT::pack(qa.alpha * (v[0] + bb[0]), qa.alpha * (v[1] + bb[1])),
+                       HT::pack(qa.alpha * (v[2] + bb[2]), qa.alpha * (v[3] + bb[3])));
       }
     }
     __syncthreads();
@@ -445,28 +468,27 @@ bool perf_attn_supported(int dh, int S) { return dh == DH && S >= 1 && S <= 224;
 bool perf_attn_qkv_supported(int dh, int S, int H) { return dh == DH && H == 4 && S >= 1 && S <= 208; }
 
 namespace {
-template <bool QKV>
+template <int QMT>
 int launch_perf_attn(uint16_t* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len, int B,
                      int S, int H, uint16_t* out, const PerfQkv& qa, hipStream_t s) {
-  const int TP = (S + 31) & ~31, TS = TP + 8, SP = (S + 15) & ~15;
+  const int TP = (S + 31) & ~31, TS = TP + 8;
   const int vreg = (TP * DH > MF * PS) ? TP * DH : MF * PS;
   int smem = (MF * TS + vreg + DH * PS) * 2;
-  if (QKV) {
-    const int stages = 2 * (SP * 128 + 384 * 128), img = SP * 768;
-    smem = smem > stages ? smem : stages;
+  if (QMT > 0) {  // phase 0: two row stages, then the [R][384] 16-bit row image
+    const int img = QMT * 16 * 768;
     smem = smem > img ? smem : img;
   }
   static DevInt attr;
   if (smem > attr) {
-    if (hipFuncSetAttribute((const void*)perf_attn_kernel<HB, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-        hipFuncSetAttribute((const void*)perf_attn_kernel<HF, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)perf_attn_kernel<HB, QMT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)perf_attn_kernel<HF, QMT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr = smem;
   }
   if (h16 == MDM_H16_F16) {
-    hipLaunchKernelGGL((perf_attn_kernel<HF, QKV>), dim3(B * H), dim3(NTH), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out, qa);
+    hipLaunchKernelGGL((perf_attn_kernel<HF, QMT>), dim3(B * H), dim3(NTH), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out, qa);
   } else {
-    hipLaunchKernelGGL((perf_attn_kernel<HB, QKV>), dim3(B * H), dim3(NTH), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out, qa);
+    hipLaunchKernelGGL((perf_attn_kernel<HB, QMT>), dim3(B * H), dim3(NTH), smem, s, qkv, PT, ldp, hn_w, hn_b, len, S, H, out, qa);
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
@@ -478,7 +500,7 @@ int perf_attn(const void* qkv, int h16, const uint16_t* PT, int ldp, const float
               int S, int H, int dh, uint16_t* out, hipStream_t s) {
   if (!perf_attn_supported(dh, S) || (h16 != MDM_H16_BF16 && h16 != MDM_H16_F16)) return MDM_ERR_UNSUPPORTED;
   if (!qkv || !PT || !hn_w || !hn_b || !len || !out || (ldp & 7)) return MDM_ERR_ARG;
-  return launch_perf_attn<false>((uint16_t*)qkv, h16, PT, ldp, hn_w, hn_b, len, B, S, H, out, PerfQkv(), s);
+  return launch_perf_attn<0>((uint16_t*)qkv, h16, PT, ldp, hn_w, hn_b, len, B, S, H, out, PerfQkv(), s);
 }
 
 // the same with the q | k | v projection inside: xn 16-bit [B S, D] (format h16), wqkv the 16-bit plane [3 D][ldw] of the stacked
@@ -491,7 +513,9 @@ int perf_attn_qkv(const uint16_t* xn, const uint16_t* wqkv, int ldw, const float
       ((((uintptr_t)xn) | ((uintptr_t)wqkv) | ((uintptr_t)qscratch)) & 15))
     return MDM_ERR_ARG;
   const PerfQkv qa = {xn, wqkv, ldw, bias, alpha};
-  return launch_perf_attn<true>(qscratch, h16, PT, ldp, hn_w, hn_b, len, B, S, H, out, qa, s);
+  // 7 row tiles cover the coarse scale (S <= 112), 13 the full one: the count is compiled in (see QkvGeo)
+  if (S <= 112) return launch_perf_attn<7>(qscratch, h16, PT, ldp, hn_w, hn_b, len, B, S, H, out, qa, s);
+  return launch_perf_attn<13>(qscratch, h16, PT, ldp, hn_w, hn_b, len, B, S, H, out, qa, s);
 }
 
 }  // namespace mdm
