@@ -102,16 +102,18 @@ __device__ __forceinline__ void qkv_slice(int kk, u32x4 (&st)[QkvGeo<MT>::NCH], 
   __syncthreads();
   if (kk + 1 < 8) qkv_fetch<NCH>(st, to, R, S, D, kk + 1, xrow0);
   const uint8_t* xb = stage + r16 * 128;
-  frag_t xf[2];
-  xf[0] = *(const frag_t*)(xb + (((q) ^ ((r16 >> 1) & 7)) << 4));
+  constexpr int NA = 4, PD = NA - 1;  // row-fragment ring: PD fragments ahead of the MFMAs (one ahead leaves half the LDS latency exposed)
+  frag_t xf[NA];
+#pragma unroll
+  for (int n = 0; n < PD; ++n) xf[n] = *(const frag_t*)(xb + (n % MT) * 2048 + ((((n / MT) * 4 + q) ^ ((r16 >> 1) & 7)) << 4));
 #pragma unroll
   for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int n = k2 * MT + mt + 1;  // the fragment after this one: (step n / MT, row tile n % MT)
-      if (n < 2 * MT) xf[n & 1] = *(const frag_t*)(xb + (n % MT) * 2048 + ((((n / MT) * 4 + q) ^ ((r16 >> 1) & 7)) << 4));
+      const int c = k2 * MT + mt, n = c + PD;  // this fragment, and the one requested now: (step n / MT, row tile n % MT)
+      if (n < 2 * MT) xf[n % NA] = *(const frag_t*)(xb + (n % MT) * 2048 + ((((n / MT) * 4 + q) ^ ((r16 >> 1) & 7)) << 4));
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[mt][j] = HT::mfma16(wr[3 * k2 + j], xf[(n - 1) & 1], acc[mt][j]);  // lane: row 16 mt + r16, cols 16 ct + 4 q ..
+      for (int j = 0; j < 3; ++j) acc[mt][j] = HT::mfma16(wr[3 * k2 + j], xf[c % NA], acc[mt][j]);  // lane: row 16 mt + r16, cols 16 ct + 4 q ..
       if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
     int nxt = 2 * kk + k2 + 2;  // the K step this slot holds next (past the end: re-read the last one, never used)
