@@ -408,7 +408,8 @@ int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
  * instead of the streamed-weight one (csrc/mlp_stream.hip; 41-49 that kernel's timing-only knock-outs and its stamped build:
  * results are wrong under them); 32 / 33 the Performer proj_out pair / the 4x FFN pair as two GEMMs; 30 stylization input and
  * its Linear as two launches, 29 that kernel on 64-row tiles, 35 the Performer tail as its own launches instead of inside the proj_out
- * pair's launch, 50 the Performer's q | k | v projection as its own GEMM launch instead of inside the attention core's; 22 unfolded text cross-attention, 24 folded at any pass count;
+ * pair's launch, 50 the Performer's q | k | v projection as its own GEMM launch instead of inside the attention core's, 51 the same for
+ * the query of the linear cross-attention; 22 unfolded text cross-attention, 24 folded at any pass count;
  * 23 generic head_dim-256 paths; 25 fp32 instead of 16-bit intermediates; 26 / 27 router with compile-time / run-time expert
  * count wherever both exist; 31 input embedding in the mode's own precision; 36 fp32-grade Linears on the register-staged
  * kernel, 37-39 ring depths of the LDS-DMA fp32-grade kernel. */

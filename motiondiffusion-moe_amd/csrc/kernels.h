@@ -62,6 +62,9 @@ int sd_attn(const void* q, int q_fmt, const float* kc, const float* vc, int B, i
             float* out32, int h16, hipStream_t s, const int32_t* ntok = nullptr);  // ntok: per-sample token counts [B] or null
 int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, int dh, float* out, uint16_t* out16,
               int h16, hipStream_t s);
+bool lin_xattn_q_supported(int dh, int S, int H);
+int lin_xattn_q(const uint16_t* xn, const uint16_t* wq, int ldw, const float* bq, const float* at, int B, int S, int H, int dh, float* out,
+                uint16_t* out16, int h16, hipStream_t s);
 // sdfold.hip: text cross-attention with folded projections + the following LayerNorm, one launch
 bool sd_fold_supported(int D, int H, int N);
 int sd_fold_heads_per_pass(int H, int N);  // whole heads per pass of <= 128 folded columns

@@ -388,8 +388,14 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
   if (!pre_normed) MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
   const bool fused = c.bf && lin_xattn_supported(dh) && !(dh == 256 && g_bf16_variant == 23);  // knob 23: big-width generic paths
   bool x16o = false;
-  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
-  if (fused) {
+  // head_dim 128: the query projection inside the attention launch (csrc/xattn.hip lin_xattn_q; knob 51: its own GEMM launch)
+  const bool q_in = fused && g_bf16_variant != 51 && D == 512 && lin_xattn_q_supported(dh, c.S, H);
+  if (!q_in) MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
+  if (q_in) {
+    x16o = g_bf16_variant != 25;
+    MDM_TRY(lin_xattn_q((const uint16_t*)w.t2, l.ca_q.hi, (int)l.ca_q.ld, l.ca_q_b, at, c.B, c.S, H, dh, x16o ? nullptr : w.t4,
+                        x16o ? (uint16_t*)w.t4 : nullptr, c.h16, c.s));
+  } else if (fused) {
     x16o = g_bf16_variant != 25;  // consumed by the stylization LayerNorm only: bf16
     MDM_TRY(lin_xattn(w.t3, c.h16, at, c.B, c.S, H, dh, x16o ? nullptr : w.t4, x16o ? (uint16_t*)w.t4 : nullptr, c.h16, c.s));  // (:248,253)
   } else {

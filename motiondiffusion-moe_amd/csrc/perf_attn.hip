@@ -14,6 +14,7 @@
 // LDS: kphi^T 128 x (TP+8) 16-bit (row stride/16 B odd => conflict-free fragment reads), v TP x 128, P^T 128 x 136 resident;
 // KV^T (128 x 136) takes the v region once v is dead.  151,552 B at T = 196.
 #include "kernels.h"
+#include "proj_phase.h"
 
 namespace mdm {
 namespace {
@@ -25,7 +26,6 @@ __device__ __forceinline__ int voff(int row, int ch) { return 256 * row + 16 * (
 
 constexpr int DH = 128, MF = 128, PS = 136, NW = 8, NTH = 64 * NW;  // 8 waves: <= 2 row tiles per wave per phase  // PS: padded row stride (elements) of the 128-wide LDS images
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename HT>
 __device__ __forceinline__ typename HT::frag_t make_frag(const float* x) {
@@ -50,78 +50,6 @@ struct PerfQkv {
   const float* bias;  // [3 D]
   float alpha;
 };
-
-// phase-0 staging of one K slice (64 columns) of the sample's xn rows: global -> registers -> LDS (free functions on purpose: an
-// array captured by a lambda keeps its stack slot = scratch memory).  Branch-free loads: chunk ids past the end re-read the last
-// chunk and are not landed.  16-B chunk c of row r at slot c ^ ((r >> 1) & 7): two 128-B rows span the 64 banks, so the 16 rows of
-// a fragment read are conflict-free when the 8 rows of either parity take 8 different slots.
-template <int NCH>
-__device__ __forceinline__ void qkv_fetch(u32x4 (&st)[NCH], int tid, int R, int S, int D, int kk, const uint16_t* __restrict__ xrow0) {
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    int id = tid + NTH * i;
-    id = id < R * 8 ? id : R * 8 - 1;
-    int row = id >> 3;
-    row = row < S ? row : S - 1;
-    st[i] = *(const u32x4*)(xrow0 + (int64_t)row * D + kk * 64 + (id & 7) * 8);
-  }
-}
-template <int NCH>
-__device__ __forceinline__ void qkv_land(const u32x4 (&st)[NCH], int tid, int R, uint8_t* stage) {
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int id = tid + NTH * i;
-    if (id < R * 8) {
-      const int row = id >> 3;
-      *(u32x4*)(stage + row * 128 + ((((id & 7)) ^ ((row >> 1) & 7)) << 4)) = st[i];
-    }
-  }
-}
-
-// Row tiles the fused form holds: 13 (S <= 208: the [R][384] row image must fit the LDS) or 7 (S <= 112, the coarse scale).  The
-// count is a template argument: with a run-time bound every row tile is its own basic block and its fragment read is waited for
-// right in front of its three MFMAs.
-template <int MT>
-struct QkvGeo {
-  static constexpr int R = MT * 16;                       // rows staged and multiplied (rows >= S: copies of the last row)
-  static constexpr int NCH = (R * 8 + NTH - 1) / NTH;     // 16-B chunks per thread and K slice
-};
-
-// one K slice (two K steps of 32): land its rows in `stage`, barrier, request the next slice into the same registers, MFMAs.
-// wr: the wave's weight ring, 3 fragments per K step x 2 steps; a slot is refilled with the fragment two steps ahead right after use.
-// The row fragments go through two registers, one read ahead of the MFMAs, pinned per row tile.
-template <typename HT, int MT, bool PIN = true>
-__device__ __forceinline__ void qkv_slice(int kk, u32x4 (&st)[QkvGeo<MT>::NCH], f32x4 (&acc)[MT][3], typename HT::frag_t (&wr)[6],
-                                          const uint16_t* const (&wrow)[3], uint8_t* stage, int tid, int r16, int q, int S, int D,
-                                          const uint16_t* __restrict__ xrow0) {
-  typedef typename HT::frag_t frag_t;
-  constexpr int R = QkvGeo<MT>::R, NCH = QkvGeo<MT>::NCH;
-  int to = tid;  // opaque per slice: hoisted out of the K loop the staging addresses would be spilled
-  asm volatile("" : "+v"(to));
-  qkv_land<NCH>(st, to, R, stage);
-  __syncthreads();
-  if (kk + 1 < 8) qkv_fetch<NCH>(st, to, R, S, D, kk + 1, xrow0);
-  const uint8_t* xb = stage + r16 * 128;
-  constexpr int NA = 4, PD = NA - 1;  // row-fragment ring: PD fragments ahead of the MFMAs (one ahead leaves half the LDS latency exposed)
-  frag_t xf[NA];
-#pragma unroll
-  for (int n = 0; n < PD; ++n) xf[n] = *(const frag_t*)(xb + (n % MT) * 2048 + ((((n / MT) * 4 + q) ^ ((r16 >> 1) & 7)) << 4));
-#pragma unroll
-  for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int c = k2 * MT + mt, n = c + PD;  // this fragment, and the one requested now: (step n / MT, row tile n % MT)
-      if (n < 2 * MT) xf[n % NA] = *(const frag_t*)(xb + (n % MT) * 2048 + ((((n / MT) * 4 + q) ^ ((r16 >> 1) & 7)) << 4));
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[mt][j] = HT::mfma16(wr[3 * k2 + j], xf[c % NA], acc[mt][j]);  // lane: row 16 mt + r16, cols 16 ct + 4 q ..
-      if (PIN) __builtin_amdgcn_sched_barrier(0);
-    }
-    int nxt = 2 * kk + k2 + 2;  // the K step this slot holds next (past the end: re-read the last one, never used)
-    nxt = nxt < 16 ? nxt : 15;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) wr[3 * k2 + j] = *(const frag_t*)(wrow[j] + 32 * nxt);
-  }
-}
 
 template <typename HT, int QMT>  // QMT: 0 = q | k | v rows read from memory; 7 / 13 = computed here for that many row tiles
 __global__ __launch_bounds__(NTH) void perf_attn_kernel(uint16_t* __restrict__ qkv, const uint16_t* __restrict__ PT,
@@ -226,7 +154,7 @@ __global__ __launch_bounds__(NTH) void perf_attn_kernel(uint16_t* __restrict__ q
     u32x4 sa[NCH];
     qkv_fetch<NCH>(sa, tid, R, S, D, 0, xrow0);
 #pragma unroll 1
-    for (int kk = 0; kk < 8; ++kk) qkv_slice<HT, MT>(kk, sa, acc, wr, wrow, smem_raw + (kk & 1) * (R * 128), tid, r16, q, S, D, xrow0);
+    for (int kk = 0; kk < 8; ++kk) qkv_slice<HT, MT, 3>(kk, sa, acc, wr, wrow, smem_raw + (kk & 1) * (R * 128), tid, r16, q, S, D, xrow0);
     __syncthreads();  // the stages are dead: their LDS takes the q | k | v rows
     // rows as 16-bit [R][384] (768-B rows; 16-B chunk c at slot c ^ (row & 15), inside its group of 16 chunks)
 #pragma unroll

@@ -5,6 +5,7 @@
 // 8 consecutive k per lane group), products are taken with the operands swapped so that each lane ends up with
 // 4 consecutive output features of ONE row; the score accumulator is reused as the B operand of the value product.
 #include "kernels.h"
+#include "proj_phase.h"
 
 namespace mdm {
 namespace {
@@ -12,7 +13,6 @@ namespace {
 constexpr int DH = 128, PS = 136, NP = 96, NS = NP + 8;  // NS: row stride (elements) of the v^T image
 constexpr int XNT = 512;  // threads per (batch, head) workgroup: 8 waves share the <= 14 row tiles
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename HT>
 __device__ __forceinline__ typename HT::frag_t make_frag(const float* x) {
@@ -205,6 +205,107 @@ __global__ __launch_bounds__(XNT) void lin_xattn_kernel(const void* __restrict__
   }
 }
 
+
+// The linear cross attention with its query projection inside (16-bit modes, head_dim 128, D = 512): the workgroup of (batch,
+// head) first multiplies its sample's normed rows with its head's 128 rows of the query weight (proj_phase.h: one column tile
+// per wave, all MT row tiles), leaves q + b as 16-bit rows in LDS (the rounding point of the separate GEMM launch), and every wave
+// then takes its own row tiles through softmax over head_dim and the product with A^T as above.  The [M, D] query tensor and its
+// launch are gone.
+template <typename HT, int MT>
+__global__ __launch_bounds__(XNT) void lin_xattn_q_kernel(const uint16_t* __restrict__ xn, const uint16_t* __restrict__ wq, int ldw,
+                                                          const float* __restrict__ bq, const float* __restrict__ at, int S, int H,
+                                                          float* __restrict__ out, uint16_t* __restrict__ out16) {
+  typedef typename HT::frag_t frag_t;
+  constexpr int R = QkvGeo<MT>::R, NCH = QkvGeo<MT>::NCH;
+  constexpr int WORK_B = 2 * R * 128 > R * 256 ? 2 * R * 128 : R * 256;  // two row stages, then the q image [R][128] (256-B rows)
+  extern __shared__ __attribute__((aligned(1024))) uint8_t xq_smem[];
+  uint8_t* const aL = xq_smem + WORK_B;  // A^T [l][d], 256-B rows
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, D = H * DH;
+  const float* ab = at + (int64_t)blockIdx.x * DH * DH;
+  for (int i = tid; i < DH * (DH / 4); i += XNT) {
+    const int l = i / (DH / 4), c = i - l * (DH / 4);
+    const f32x4 v = *(const f32x4*)(ab + l * DH + 4 * c);
+    *(uint2*)(aL + l * 256 + (((c >> 1) ^ (l & 15)) << 4) + (c & 1) * 8) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
+  }
+  // ---- query rows of this head: [R x 128] = xn[b] . Wq_h^T --------------------------------------------------------------------
+  {
+    const uint16_t* xrow0 = xn + (int64_t)b * S * D;
+    const uint16_t* wrow[1] = {wq + (int64_t)(h * DH + 16 * wid + r16) * ldw + 8 * q};
+    frag_t wr[2];
+    wr[0] = *(const frag_t*)(wrow[0]);
+    wr[1] = *(const frag_t*)(wrow[0] + 32);
+    f32x4 acc[MT][1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 sa[NCH];
+    qkv_fetch<NCH>(sa, tid, R, S, D, 0, xrow0);
+#pragma unroll 1
+    for (int kk = 0; kk < 8; ++kk) qkv_slice<HT, MT, 1>(kk, sa, acc, wr, wrow, xq_smem + (kk & 1) * (R * 128), tid, r16, q, S, D, xrow0);
+    __syncthreads();  // the stages are dead: their LDS takes the q rows
+    const int col = 16 * wid + 4 * q;
+    const f32x4 bb = *(const f32x4*)(bq + h * DH + col);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = 16 * mt + r16;
+      const f32x4 v = acc[mt][0];
+      *(uint2*)(xq_smem + row * 256 + ((((col >> 3)) ^ (row & 15)) << 4) + ((col >> 2) & 1) * 8) =
+          make_uint2(HT::pack(v[0] + bb[0], v[1] + bb[1]), HT::pack(v[2] + bb[2], v[3] + bb[3]));
+    }
+  }
+  __syncthreads();
+  const int ntile = (S + 15) >> 4;
+  for (int tile = wid; tile < ntile; tile += XNT / 64) {
+    const int row = tile * 16 + r16, t = row;
+    float x[32];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // the row in the fragment layout: k = 32 ks + 8 q + j
+      const uint4 u = *(const uint4*)(xq_smem + row * 256 + (((4 * ks + q) ^ (row & 15)) << 4));
+      x[8 * ks + 0] = HT::lo(u.x), x[8 * ks + 1] = HT::hi(u.x);
+      x[8 * ks + 2] = HT::lo(u.y), x[8 * ks + 3] = HT::hi(u.y);
+      x[8 * ks + 4] = HT::lo(u.z), x[8 * ks + 5] = HT::hi(u.z);
+      x[8 * ks + 6] = HT::lo(u.w), x[8 * ks + 7] = HT::hi(u.w);
+    }
+    float mx = -INFINITY;  // softmax over head_dim (:248)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) mx = fmaxf(mx, x[i]);
+    mx = quad_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      x[i] = exp_fast(x[i] - mx);
+      sum += x[i];
+    }
+    const float inv = 1.f / quad_sum(sum);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] *= inv;
+    frag_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = make_frag<HT>(x + 8 * ks);
+    f32x4 y[8];
+#pragma unroll
+    for (int lt = 0; lt < 8; ++lt) y[lt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int lt = 0; lt < 8; ++lt) {
+        const int ar = 16 * lt + r16;
+        const frag_t af = *(const frag_t*)(aL + ar * 256 + (((4 * ks + q) ^ (ar & 15)) << 4));
+        y[lt] = HT::mfma16(af, qf[ks], y[lt]);  // D[l][t]
+      }
+    if (t < S && out16) {
+      uint16_t* orow = out16 + ((int64_t)b * S + t) * D + h * DH;
+#pragma unroll
+      for (int lt = 0; lt < 8; ++lt)
+        *(uint2*)(orow + 16 * lt + 4 * q) = make_uint2(HT::pack(y[lt][0], y[lt][1]), HT::pack(y[lt][2], y[lt][3]));
+    } else if (t < S) {
+      float* orow = out + ((int64_t)b * S + t) * D + h * DH;
+#pragma unroll
+      for (int lt = 0; lt < 8; ++lt) *(f32x4*)(orow + 16 * lt + 4 * q) = y[lt];
+    }
+  }
+}
+
 // the same at head_dim 256 (big model): A^T [256][264] fills 132 KiB of LDS (dynamic), 64 elements of q per lane
 constexpr int DH2 = 256, PS2 = 264;
 template <typename HT, bool IN16>
@@ -367,6 +468,41 @@ int lin_xattn(const void* ql, int ql_fmt, const float* at, int B, int S, int H, 
   }
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
+}
+
+// the same with the query projection inside (16-bit modes, head_dim 128, H = 4): xn 16-bit [B S, D] (format h16), wq the 16-bit plane
+// [D][ldw] of the query weight, bq [D]
+bool lin_xattn_q_supported(int dh, int S, int H) { return dh == DH && H == 4 && S >= 1 && S <= 208; }
+
+namespace {
+template <int MT>
+int launch_lin_xattn_q(const uint16_t* xn, const uint16_t* wq, int ldw, const float* bq, const float* at, int B, int S, int H, float* out,
+                       uint16_t* out16, int h16, hipStream_t s) {
+  constexpr int R = QkvGeo<MT>::R;
+  constexpr int smem = (2 * R * 128 > R * 256 ? 2 * R * 128 : R * 256) + DH * 256;
+  static DevOnce attr;
+  if (smem > 65536 && !attr) {
+    if (hipFuncSetAttribute((const void*)lin_xattn_q_kernel<HF, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lin_xattn_q_kernel<HB, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return MDM_ERR_LAUNCH;
+    attr = true;
+  }
+  if (h16 == MDM_H16_F16) {
+    hipLaunchKernelGGL((lin_xattn_q_kernel<HF, MT>), dim3(B * H), dim3(XNT), smem, s, xn, wq, ldw, bq, at, S, H, out, out16);
+  } else {
+    hipLaunchKernelGGL((lin_xattn_q_kernel<HB, MT>), dim3(B * H), dim3(XNT), smem, s, xn, wq, ldw, bq, at, S, H, out, out16);
+  }
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+}  // namespace
+
+int lin_xattn_q(const uint16_t* xn, const uint16_t* wq, int ldw, const float* bq, const float* at, int B, int S, int H, int dh, float* out,
+                uint16_t* out16, int h16, hipStream_t s) {
+  if (!lin_xattn_q_supported(dh, S, H) || (h16 != MDM_H16_BF16 && h16 != MDM_H16_F16)) return MDM_ERR_UNSUPPORTED;
+  if (!xn || !wq || !bq || !at || (!out && !out16) || (ldw & 7) || ((((uintptr_t)xn) | ((uintptr_t)wq)) & 15)) return MDM_ERR_ARG;
+  if (S <= 112) return launch_lin_xattn_q<7>(xn, wq, ldw, bq, at, B, S, H, out, out16, h16, s);
+  return launch_lin_xattn_q<13>(xn, wq, ldw, bq, at, B, S, H, out, out16, h16, s);
 }
 
 }  // namespace mdm

@@ -239,6 +239,28 @@ def test_qkv_projection_inside_the_attention_core(B, S, precision):
     assert e_f < TOL[precision] and e_s < TOL[precision]
 
 
+@pytest.mark.parametrize("precision", [2, 1])
+@pytest.mark.parametrize("B,S,N", [(2, 98, 28), (3, 37, 6), (1, 5, 9), (2, 196, 28), (2, 208, 85)])
+def test_query_projection_inside_the_linear_cross_attention(B, S, N, precision):
+    """16-bit modes, head_dim 128: the query projection of GatedCrossAttention runs inside the attention launch
+    (csrc/xattn.hip lin_xattn_q); knob 51 runs it as its own GEMM launch.  Same products, same 16-bit rounding of q."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, precision)
+    L = pkg("_lib")
+    fused = _run_block(m, L.BLOCK_CROSS, h, sc, length, xf)
+    L.lib().mdm_set_gemm_variant(51)
+    try:
+        split = _run_block(m, L.BLOCK_CROSS, h, sc, length, xf)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    with torch.no_grad():
+        ref = R.gated_cross_attention(h, xf, emb, sd, pre + ".cross_attn", H, eph["low.0.cross_style"])
+    d, e_f, e_s = rel_inf(fused, split), rel_inf(fused, ref), rel_inf(split, ref)
+    print(f"B={B} S={S} N={N} precision {precision}: query inside vs own launch {d:.2e}; vs oracle {e_f:.2e} / {e_s:.2e}")
+    assert torch.isfinite(fused).all()
+    assert d < (1e-3 if precision == 2 else 8e-3)
+    assert e_f < TOL[precision] and e_s < TOL[precision]
+
+
 @pytest.mark.parametrize("precision", [3, 1, 2, 4])
 def test_named_block_entry_points(precision):
     """The per-block C entry points named in SURVEY.md §8(b): the aliases must reproduce mdm_block_forward bit for bit, and
