@@ -109,12 +109,14 @@ def test_grouped_gathered_fp8_mlp_chain():
     assert torch.all(out[M:] == 7.0)
 
 
-def test_configs4_big_16_experts_fp8_mode_error_and_flips():
-    """Big widths (D 1024, F 2048, head_dim 256), E = 16, top-2, fp8 expert GEMMs, L = 2 (4 decoder layers), B = 8, T = 64:
-    the fp8 mode against the oracle -- error and routing decisions that differ are printed and held to a budget; the fp16 mode
-    on the same inputs is printed beside it so the cost of fp8 is visible."""
+@pytest.mark.parametrize("Ln,T", [(2, 64), (4, 196)])
+def test_configs4_big_16_experts_fp8_mode_error_and_flips(Ln, T):
+    """Big widths (D 1024, F 2048, head_dim 256), E = 16, top-2, fp8 expert GEMMs, B = 8 -- at a reduced shape (L = 2, T = 64) and
+    at BASELINE configs[4]'s real per-GPU shape (L = 4: 8 decoder layers, B = 64 / 8 GPUs = 8, T = 196): the fp8 mode against the
+    oracle -- error and routing decisions that differ are printed and held to a budget; the fp16 mode on the same inputs is
+    printed beside it so the cost of fp8 is visible."""
     T_, synth = pkg("transformer"), pkg("synth")
-    B, T, E, Ln = 8, 64, 16, 2
+    B, E = 8, 16
     res = {}
     host = None
     for precision in (5, 2):
