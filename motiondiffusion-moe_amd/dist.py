@@ -70,7 +70,13 @@ def sample_sharded(sample_fn, shape, model_kwargs: Dict, seed: int, group=None):
     B = shape[0]
     lo, hi = shard_range(B, rank, world)
     local_kw = shard_kwargs(model_kwargs, lo, hi)
-    local = sample_fn((hi - lo,) + tuple(shape[1:]), local_kw, seed, lo)
+    if hi > lo:
+        local = sample_fn((hi - lo,) + tuple(shape[1:]), local_kw, seed, lo)
+    else:
+        # more ranks than samples: this rank has nothing to denoise but still takes part in the gather (on the device the
+        # others produce their shards on: that of the conditioning tensors)
+        dev = next((v.device for v in model_kwargs.values() if isinstance(v, torch.Tensor)), torch.device("cpu"))
+        local = torch.empty((0,) + tuple(shape[1:]), dtype=torch.float32, device=dev)
     return all_gather_ragged(local, B, group)
 
 

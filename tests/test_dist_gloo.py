@@ -1,4 +1,4 @@
-"""CPU, world_size 2 (gloo): batch sharding + the path's single all_gather give world-size independent results."""
+"""CPU, world_size 2 and 3 (gloo): batch sharding + the path's single all_gather give world-size independent results."""
 import os
 import socket
 
@@ -47,14 +47,15 @@ def _worker(rank, world, port, B, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [4, 5])
-def test_sharded_sampling_is_world_size_invariant(tmp_path, B):
+@pytest.mark.parametrize("B,world", [(4, 2), (5, 2), (5, 3), (2, 3)])
+def test_sharded_sampling_is_world_size_invariant(tmp_path, B, world):
+    """(5, 3): ragged shards 2 | 2 | 1; (2, 3): the last rank holds no sample and still takes part in the gather."""
     dmod = pkg("dist")
     kw = {"length": torch.arange(B) + 3, "xf_proj": torch.arange(B * 2, dtype=torch.float32).view(B, 2),
           "text": [f"t{i}" for i in range(B)], "scalar": 5}
     single = dmod.sample_sharded(_fake_sampler, (B, 4, 3), kw, seed=7)
     out = str(tmp_path / "y.pt")
-    mp.spawn(_worker, args=(2, _free_port(), B, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
     assert torch.equal(torch.load(out), single)
 
 
