@@ -405,15 +405,22 @@ int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
 /* Kernel-selection knob for same-box A/B runs and tests (0 = default; process-global, not thread-safe, never part of the data
  * path).  Values: 1 / 2 force the 128- / 64-row tile of the 16-bit GEMM, 6 / 7 force / forbid its 256 x 256 tile, 28 two-stage
  * ring in the 64-row tile; 21 expert MLP as two GEMMs instead of the fused kernel, 34 the LDS-staged fused kernel (csrc/mlp.hip)
- * instead of the streamed-weight one (csrc/mlp_stream.hip; 41-49 that kernel's timing-only knock-outs and its stamped build:
- * results are wrong under them); 32 / 33 the Performer proj_out pair / the 4x FFN pair as two GEMMs; 30 stylization input and
+ * instead of the streamed-weight one (csrc/mlp_stream.hip); 32 / 33 the Performer proj_out pair / the 4x FFN pair as two GEMMs; 30 stylization input and
  * its Linear as two launches, 29 that kernel on 64-row tiles, 35 the Performer tail as its own launches instead of inside the proj_out
  * pair's launch, 50 the Performer's q | k | v projection as its own GEMM launch instead of inside the attention core's, 51 the same for
  * the query of the linear cross-attention; 22 unfolded text cross-attention, 24 folded at any pass count;
  * 23 generic head_dim-256 paths; 25 fp32 instead of 16-bit intermediates; 26 / 27 router with compile-time / run-time expert
  * count wherever both exist; 31 input embedding in the mode's own precision; 36 fp32-grade Linears on the register-staged
- * kernel, 37-39 ring depths of the LDS-DMA fp32-grade kernel. */
+ * kernel, 37-39 ring depths of the LDS-DMA fp32-grade kernel.
+ * 41-49 (timing-only knock-outs and the stamped build of the fused expert MLP: outputs are WRONG under them) exist only in the
+ * diagnostic library (-DMDM_DIAG: `python motiondiffusion-moe_amd/build.py --diag` -> libmdm_hip_diag.so, used by tools/mlp_ko.py
+ * and tools/mlp_stamps.py); libmdm_hip.so returns MDM_ERR_ARG for them and leaves the knob unchanged. */
 int mdm_set_gemm_variant(int variant);
+/* 1 in the diagnostic library, 0 in the product library */
+int mdm_diag_build(void);
+/* diagnostic library only (MDM_ERR_UNSUPPORTED otherwise): the eight 64-bit device counters that the stamped build of the fused
+ * expert MLP (knob 49) adds its per-phase cycle sums to; NULL detaches them (knob 49 is then refused with MDM_ERR_ARG). */
+int mdm_diag_mlp_counters(uint64_t* dev_counters8);
 /* diagnostic: s_memtime stamps of block 0 of the last bf16 GEMM launched with feat_S == -77 (host copy, synchronises) */
 int mdm_debug_stamps(uint64_t* out16);
 

@@ -35,15 +35,44 @@ __global__ void pack_f16_kernel(const float* __restrict__ src, int64_t ld_src, i
 }  // namespace
 }  // namespace mdm
 
-namespace mdm { extern int g_bf16_variant; int debug_stamps(unsigned long long* out); }
+namespace mdm {
+extern int g_bf16_variant;
+int debug_stamps(unsigned long long* out);
+#ifdef MDM_DIAG
+extern unsigned long long* g_diag_counters;
+#endif
+}
 
 extern "C" {
 
 int mdm_debug_stamps(uint64_t* out16) { return mdm::debug_stamps((unsigned long long*)out16); }
 
 int mdm_set_gemm_variant(int v) {
+#ifndef MDM_DIAG
+  // 41..49: knock-outs / stamped builds of the fused expert MLP whose outputs are wrong by construction.  They exist only in
+  // the diagnostic library (-DMDM_DIAG, `build.py --diag`); the product library refuses the knob instead of computing garbage.
+  if (v >= 41 && v <= 49) return MDM_ERR_ARG;
+#endif
   mdm::g_bf16_variant = v;
   return MDM_OK;
+}
+
+int mdm_diag_build(void) {
+#ifdef MDM_DIAG
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+int mdm_diag_mlp_counters(uint64_t* dev_counters8) {
+#ifdef MDM_DIAG
+  mdm::g_diag_counters = (unsigned long long*)dev_counters8;
+  return MDM_OK;
+#else
+  (void)dev_counters8;
+  return MDM_ERR_UNSUPPORTED;
+#endif
 }
 
 const char* mdm_version(void) { return "mdm_hip 0.1 (gfx950)"; }

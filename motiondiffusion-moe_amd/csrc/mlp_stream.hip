@@ -175,8 +175,9 @@ __device__ __forceinline__ void store_tile(const MdmMlpDesc& g, f32x4 (&y)[RT][N
   }
 }
 
-// Diagnostic build KO == 9 (knob 49, tools/mlp_stamps.py): wave 0 of every workgroup sums s_memtime differences per phase and
-// adds them to the eight 64-bit counters that the R2 pointer of the descriptor points at (R2 is not read as a residual then).
+// Diagnostic build KO == 9 (-DMDM_DIAG library only, knob 49, tools/mlp_stamps.py): wave 0 of every workgroup sums s_memtime
+// differences per phase and adds them to the eight 64-bit counters handed over through mdm_diag_mlp_counters() (a buffer of
+// their own: no output or residual pointer is reused for them; the launch is refused while none is set).
 // Read the SHARES of this build, not its run time.
 __device__ __forceinline__ unsigned long long stamp_now() {
   unsigned long long t;
@@ -383,9 +384,11 @@ __device__ __forceinline__ void pair_tail(const PairTail& st, f32x4 (&y)[RT][4],
   }
 }
 
-// KO: timing-only knock-outs for tools/mlp_ko.py (0 = the real kernel; results are wrong otherwise): 1 no GELU arithmetic,
-// 2 no weight refills, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores; 7 = the real kernel with the erf-form GELU
-// of the LDS-staged kernel; 8 = GELU pieces interleaved with the phase-2 MFMAs of the same wave; 9 = stamped build
+// KO: 0 = the real kernel, 10 = the real kernel + the Performer tail.  Every other value exists only in the diagnostic library
+// (built with -DMDM_DIAG by `python motiondiffusion-moe_amd/build.py --diag`; the shipped libmdm_hip.so neither instantiates them
+// nor accepts their knobs): timing-only knock-outs for tools/mlp_ko.py whose results are wrong -- 1 no GELU arithmetic, 2 no
+// weight refills, 4 no phase-1 MFMAs, 5 no phase-2 MFMAs, 6 no output stores -- and A/B arms: 7 = the erf-form GELU of the
+// LDS-staged kernel, 8 = GELU pieces interleaved with the phase-2 MFMAs of the same wave, 9 = stamped build
 template <typename HT, int RT, int NJ, int DIN, int KO>
 __global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDesc g, const int tile_h, const PairTail st) {
   typedef typename HT::frag_t frag_t;
@@ -662,11 +665,9 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDes
     if constexpr (TAIL) {
       pair_tail<HT, RT, NR>(st, y, R, smem, row0, row_end, te, wn);
     } else if constexpr (KO == 9) {
-      MdmMlpDesc g2 = g;
-      g2.R2 = nullptr;
-      store_tile<HT, RT, NJ, G::SMEM, KO>(g2, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
+      store_tile<HT, RT, NJ, G::SMEM, KO>(g, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
       XSTAMP(6);
-      if (te == 0) atomicAdd((unsigned long long*)g.R2 + 7, 1ull);
+      if (te == 0) atomicAdd((unsigned long long*)st.out + 7, 1ull);  // st.out: the diagnostic counters (launcher below)
     } else {
       store_tile<HT, RT, NJ, G::SMEM, KO>(g, y, smem, row0, row_end, te, wn, te & 15, (te & 63) >> 4);
     }
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(NT, 2) void fused_mlp_stream_kernel(const MdmMlpDes
   if constexpr (KO == 9) {
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int q = 0; q < 7; ++q) atomicAdd((unsigned long long*)g.R2 + q, acc[q]);
+      for (int q = 0; q < 7; ++q) atomicAdd((unsigned long long*)st.out + q, acc[q]);
     }
   }
 }
@@ -783,6 +784,9 @@ int mlp_stream_tile_h(int64_t M, int rt_max) {
 }
 
 extern int g_bf16_variant;
+#ifdef MDM_DIAG
+unsigned long long* g_diag_counters = nullptr;  // mdm_diag_mlp_counters(): eight 64-bit device counters of the stamped build
+#endif
 
 template <int RT, int DIN, int KO, int NJ = 4>
 static int launch_stream(const MdmMlpDesc& a, int th, hipStream_t stream, const PairTail& tail = PairTail()) {
@@ -826,6 +830,7 @@ int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream) {
   }
   if (a.Din == 128) return launch_by_height<128>(a, stream);
   if (a.Din == 256) return launch_by_height<256>(a, stream);
+#ifdef MDM_DIAG
   const int th = mlp_stream_tile_h(a.M, 7);
   if (th > 64) {
     switch (g_bf16_variant) {  // knobs 41..49: knock-out / diagnostic builds for tools/mlp_ko.py, tools/mlp_stamps.py (timing only)
@@ -836,10 +841,16 @@ int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream) {
       case 46: return launch_stream<7, 512, 6>(a, th, stream);
       case 47: return launch_stream<7, 512, 7>(a, th, stream);
       case 48: return launch_stream<7, 512, 8>(a, th, stream);
-      case 49: return launch_stream<7, 512, 9>(a, th, stream);
+      case 49: {
+        if (!g_diag_counters) return MDM_ERR_ARG;  // mdm_diag_mlp_counters() first: the stamps need a buffer of their own
+        PairTail t = PairTail();
+        t.out = (float*)g_diag_counters;
+        return launch_stream<7, 512, 9>(a, th, stream, t);
+      }
       default: break;
     }
   }
+#endif
   return launch_by_height<512>(a, stream);
 }
 

@@ -273,10 +273,10 @@ class GaussianDiffusion:
     @torch.no_grad()
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, *, step_noise=None, use_graph=True,
-                         seed: Optional[int] = None, sample_offset: int = 0):
+                         seed: Optional[int] = None, sample_offset: int = 0, callback: Optional[Callable] = None):
         self._check_supported(denoised_fn, cond_fn)
         r = self._runner(model, shape, model_kwargs, device, "ddim", 0.0, eta, clip_denoised, use_graph)
-        return r.run(noise, step_noise, progress, None, seed, sample_offset)
+        return r.run(noise, step_noise, progress, callback, seed, sample_offset)
 
     # single steps (eager): same arithmetic, returns {"sample", "pred_xstart"}
     @torch.no_grad()
@@ -427,8 +427,10 @@ class _StepRunner:
         elif self.ntok is not None:  # ragged captions: a private text cache with per-row token counts
             if self.tcache is None:
                 self.tcache = self.model.prepare_text(self.xo, private=True, ntok=self.ntok)
+            # text_tokens as well: should the module's packed weights have been rebuilt since the cache was made, forward()
+            # rebuilds the text side -- with these counts, not with the zero-padded rows taken for real tokens
             self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps, stem_cache=self.stem,
-                       text_cache=self.tcache)
+                       text_cache=self.tcache, text_tokens=self.ntok)
         elif self.stem is not None:
             self.model(self.xx, self.ts, self.len2, xf_proj=self.xp, xf_out=self.xo, out=self.eps, stem_cache=self.stem)
         else:

@@ -66,7 +66,10 @@ class MoEFFNTrainer:
                  eps: float = 1e-8, max_norm: float = 1.0, dropout: float = 0.0, seed: int = 0, moe_coef: float = 0.01):
         self.D, self.F, self.E, self.Te = D, F, E, Te
         self.dropout, self.seed = float(dropout), int(seed)  # the mask of iteration i uses seed + i (see forward)
-        self.moe_coef = float(moe_coef)  # weight of the load-balancing loss (transformer.py:265-270: get_total_moe_loss)
+        # coefficient of get_total_moe_loss (transformer.py:265-270), which the reference's training path never calls: the
+        # trainer adds and logs the UNSCALED get_moe_loss (gaussian_diffusion.py:985, ddpm_trainer.py:217-222).  Only the extra
+        # "loss_moe_scaled" entry of the logged dict uses it.
+        self.moe_coef = float(moe_coef)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.MdmError("the MoE training step runs on the HIP path only (no CPU fallback)")
@@ -209,13 +212,17 @@ class MoEFFNTrainer:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.all_reduce_grads(group)
         self.optimizer_step()
-        # the load-balancing term as the reference logs it: moe_coef * sum over the block's SwitchMoELayers, from THIS
-        # forward's routing (the reference reads buffers that keep accumulating until reset_all_moe_counters is called; the
-        # unscaled per-forward value is returned beside it)
-        lb = self.lb_loss.sum()
-        moe = self.moe_coef * lb
-        return {"loss_mot_rec": float(loss.item()), "loss_moe": float(moe.item()), "loss_moe_unscaled": float(lb.item()),
-                "loss_total": float((loss + moe).item())}
+        return loss_logs(loss, self.lb_loss.sum(), self.moe_coef)
+
+
+def loss_logs(loss_mot_rec, moe_loss, moe_coef: float = 0.01) -> Dict[str, float]:
+    """The logged scalars of one iteration, keyed and combined as ``DDPMTrainer.backward_G`` does (ddpm_trainer.py:201-226):
+    ``loss_moe`` is the UNSCALED load-balancing sum over the block's SwitchMoELayers -- what ``training_losses`` stores
+    (gaussian_diffusion.py:985: ``terms['moe_loss'] = model.get_moe_loss(model)``) from THIS forward's routing -- and
+    ``loss_total = loss_mot_rec + loss_moe``, the quantity the reference back-propagates (:217, :236).  The 0.01-scaled figure
+    of ``get_total_moe_loss`` (transformer.py:265-270, not on the reference's training path) is reported beside them."""
+    rec, moe = float(loss_mot_rec), float(moe_loss)
+    return {"loss_mot_rec": rec, "loss_moe": moe, "loss_total": rec + moe, "loss_moe_scaled": moe_coef * moe}
 
 
 def all_reduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:

@@ -51,3 +51,24 @@ def test_argument_validation_without_gpu():
     assert lib.mdm_gemm(C.byref(d), None) == 1  # null operands
     assert lib.mdm_workspace_bytes(None, 1, 2, 1) == -1
     assert lib.mdm_cfg_posterior_step(None, None, None, None, C.c_int64(0), None, 0, None, 0, C.c_float(1.0), 0, None, None, None) == 1
+
+
+def test_product_library_refuses_the_diagnostic_knobs():
+    """the knock-out / stamped builds of the fused expert MLP (knobs 41..49, outputs wrong by construction) live
+    in the diagnostic library only (-DMDM_DIAG).  libmdm_hip.so returns MDM_ERR_ARG for them, leaves the knob where it was and
+    has no counter hook; every other documented knob is still accepted."""
+    import subprocess
+    L = pkg("_lib")
+    lib = L.lib()
+    assert lib.mdm_diag_build() == 0
+    assert lib.mdm_set_gemm_variant(34) == 0
+    for v in range(41, 50):
+        assert lib.mdm_set_gemm_variant(v) == 1, v  # MDM_ERR_ARG
+    assert lib.mdm_set_gemm_variant(0) == 0
+    assert lib.mdm_diag_mlp_counters(None) == 3  # MDM_ERR_UNSUPPORTED
+    # the product object holds no knock-out instantiation: template arguments <format, RT, NJ, DIN, KO> with KO in {0, 10} only
+    obj = os.path.join(ROOT, "motiondiffusion-moe_amd", "csrc", "build", "mlp_stream.o")
+    if os.path.exists(obj):
+        syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True).stdout
+        kos = set(re.findall(r"fused_mlp_stream_kernel<[^,]+, \d+, \d+, \d+, (\d+)>", syms))
+        assert kos and kos <= {"0", "10"}, kos

@@ -128,7 +128,7 @@ def test_configs1_size_independent_properties():
 
 def test_configs0_end_to_end_against_the_oracle():
     """BASELINE configs[0]: small / 4 experts / B=2 / T=64 / 50-step DDPM with CFG, fp32-grade mode.  The oracle runs the
-    whole 50-step loop (100 forwards of B=2).  Every 7th guided step of the HIP sampler is checked from the ORACLE's state
+    whole 50-step loop (100 forwards of B=2).  EVERY guided step of the HIP sampler is checked from the ORACLE's state
     (teacher forcing) and the routing of that step is dumped (mdm_route_dump) and compared with the oracle's: a step WITHOUT
     a differing decision must match at <= 1e-3; a step with one is a near-tie resolved the other way by two fp32
     implementations (an O(1) local change, not an error) and is accepted only if every differing decision sits at a token
@@ -168,7 +168,7 @@ def test_configs0_end_to_end_against_the_oracle():
         tt = torch.full((B,), t, dtype=torch.int64)
         tr_c, tr_u = {}, {}
         nxt, _ = DR.cfg_step(tb, t, xs, model(xs, tt, True, tr_c), model(xs, tt, False, tr_u), noises[i], scale)
-        if i % 7 == 0 or i == steps - 1:  # one HIP step from the oracle's state, its routing dumped
+        if True:  # EVERY step (no sampling of the gate): one HIP step from the oracle's state, its routing dumped
             lib.mdm_route_dump(C.c_void_p(dump.data_ptr()), C.c_int64(dump.numel()))
             try:
                 out = diff.p_sample_with_cfg(m, xs.cuda(), tt.cuda(), clip_denoised=False, model_kwargs=kw, cfg_scale=scale,
@@ -190,8 +190,11 @@ def test_configs0_end_to_end_against_the_oracle():
             forced.append((i, rel_inf(out["sample"].cpu(), nxt), flips, worst_gap))
         free_errs.append(rel_inf(traj[i], nxt))
         xs = nxt
-    print("teacher-forced steps (step, rel err, routing decisions that differ, largest oracle p2-p3 among them):",
-          [(i, f"{e:.1e}", f, f"{gmax:.1e}") for i, e, f, gmax in forced])
+    assert len(forced) == steps
+    print(f"teacher-forced: all {steps} steps checked; worst rel err {max(e for _, e, _, _ in forced):.1e}, "
+          f"{sum(f for _, _, f, _ in forced)} routing decisions differ in total")
+    print("every 7th (step, rel err, routing decisions that differ, largest oracle p2-p3 among them):",
+          [(i, f"{e:.1e}", f, f"{gmax:.1e}") for i, e, f, gmax in forced[::7]])
     print("free-running loop divergence at steps 0, 1, 9, 24, 49:", [f"{free_errs[i]:.1e}" for i in (0, 1, 9, 24, 49)])
     for i, e, f, gmax in forced:
         if f == 0:

@@ -189,7 +189,9 @@ def test_erf_rational_of_the_kernels_is_accurate():
 
 def test_sigmoid_form_gelu_of_the_fused_mlp_is_accurate():
     """gelu_sig2 (csrc/mdm_common.h), the GELU of the streamed-weight expert MLP: x * sigmoid(q(x)) with the header's
-    coefficients evaluated in fp32 as the kernel does; max abs error against the exact erf form over [-12, 12] < 5e-6."""
+    coefficients evaluated in fp32 as the kernel does; max abs error against the exact erf form < 5e-6 over [-12, 12] (dense),
+    [-1e4, 1e4] and the decades up to +-1e12 (beyond the clamp at 6.5 the result is x * 8.7e-20 for negative x, an
+    error linear in |x| that reaches the fit's own 3.5e-6 only at |x| ~ 4e13)."""
     import os, re
     from scipy.special import erf
     from conftest import ROOT
@@ -198,7 +200,8 @@ def test_sigmoid_form_gelu_of_the_fused_mlp_is_accurate():
     nums = [float(v) for v in re.findall(r"(-?\d\.\d+(?:e[-+]\d+)?)f", body)]
     clamp, cs = nums[:4], nums[4:14:2]
     assert clamp == [-6.5, 6.5, -6.5, 6.5] and len(cs) == 5, nums
-    x = np.linspace(-12, 12, 480001).astype(np.float32)
+    x = np.concatenate([np.linspace(-12, 12, 480001), np.linspace(-1e4, 1e4, 200001),
+                        np.array([s * 10.0 ** k for k in range(5, 13) for s in (-1.0, 1.0)])]).astype(np.float32)
     xc = np.clip(x, -6.5, 6.5)
     x2 = (xc * xc).astype(np.float32)
     p = np.full_like(x2, np.float32(cs[0]))

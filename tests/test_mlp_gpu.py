@@ -164,3 +164,57 @@ def test_streamed_weight_kernel_dense_with_residuals():
         h0 = torch.nn.functional.gelu(x16.double() @ w1.half().double().T)
         ref0 = (h0.float().half().double() @ w2.half().double().T).float()
         assert rel_inf(plain.cpu(), ref0.cpu()) < 6e-4
+
+
+def test_streamed_weight_kernel_persistent_rounds_and_in_place():
+    """what the whole-model tests exercise only at loose tolerances.  (1) 50176 routed rows in 16 ragged groups
+    (112-row tiles, RT = 7: every workgroup walks two tiles, so the `mt += gridDim.x` loop, the reuse of the LDS X image and
+    staging behind the end-of-tile barrier and xcd_remap over several rounds all run), gathered rows, fp32 + 16-bit outputs and
+    the 16-bit-only epilogue; (2) the dense in-place form proj_pair_desc uses (the 16-bit output IS the X buffer).  Both against
+    the fp64 reference with the same operand rounding."""
+    ops = pkg("ops")
+    dtype, fmt = torch.float16, "f16"
+    Din, F, Dout, G, S = 512, 1024, 512, 16, 12544
+    M = 50176
+    sizes = [3136 + 97 * ((7 * i) % 5 - 2) for i in range(G)]
+    sizes[-1] += M - sum(sizes)
+    assert sum(sizes) == M and min(sizes) > 0
+    goff = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
+    src = _rand(S, Din, seed=41).to(dtype)
+    g = torch.Generator(device="cpu").manual_seed(42)
+    gather = torch.randint(0, S, (M,), generator=g, dtype=torch.int32).cuda()
+    w1, b1 = _rand(G, F, Din, seed=43, scale=Din ** -0.5), _rand(G, F, seed=44, scale=0.1)
+    w2, b2 = _rand(G, Dout, F, seed=45, scale=F ** -0.5), _rand(G, Dout, seed=46, scale=0.1)
+    rs = _rand(M, seed=47).abs()
+    pw1, pw2 = ops.PackedWeight(w1, fmt=fmt), ops.PackedWeight(w2, fmt=fmt)
+    ws = ops.mlp_stream_pack(w1, w2, dtype)
+    out = torch.full((M + 3, Dout), 7.0, device="cuda")
+    out16 = torch.zeros((M + 3, Dout), dtype=dtype, device="cuda")
+    ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out=out, out16=out16, wstream=ws)
+    only = torch.zeros((M + 3, Dout), dtype=dtype, device="cuda")
+    ops.fused_mlp(src, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out16=only, wstream=ws, only16=True)
+    x = src[gather.long()]
+    worst = 0.0
+    o = 0
+    for e, n in enumerate(sizes):  # per group: the fp64 reference of 50176 x 1024 hidden units is taken a slab at a time
+        h = torch.nn.functional.gelu(x[o:o + n].double() @ w1[e].to(dtype).double().T + b1[e].double())
+        ref = ((h.float().to(dtype).double() @ w2[e].to(dtype).double().T + b2[e].double()) * rs[o:o + n, None].double()).float()
+        scale = float(ref.abs().max())
+        worst = max(worst, float((out[o:o + n] - ref).abs().max()) / scale)
+        assert float((out16[o:o + n].float() - ref).abs().max()) / scale < 2.4e-3, e
+        o += n
+    assert worst < 6e-4, worst
+    assert torch.all(out[M:] == 7.0) and torch.all(out16[M:] == 0) and torch.all(only[M:] == 0)
+    assert torch.equal(only.view(torch.int16), out16.view(torch.int16))
+    # (2) dense, in place: X and the 16-bit output are the same buffer (a tile's rows are resident in LDS before its stores)
+    for M2 in (12544, 6272, 100):
+        xin = _rand(M2, Din, seed=51).to(dtype)
+        wa, ba = _rand(Din, Din, seed=52, scale=Din ** -0.5), _rand(Din, seed=53, scale=0.1)
+        wb, bb = _rand(Din, Din, seed=54, scale=Din ** -0.5), _rand(Din, seed=55, scale=0.1)
+        pa, pb = ops.PackedWeight(wa, fmt=fmt), ops.PackedWeight(wb, fmt=fmt)
+        wsp = ops.mlp_stream_pack(wa, wb, dtype)
+        buf = xin.clone()
+        ops.fused_mlp(buf, pa, ba, pb, bb, out16=buf, wstream=wsp, only16=True)
+        h = torch.nn.functional.gelu(xin.double() @ wa.to(dtype).double().T + ba.double())
+        ref = (h.float().to(dtype).double() @ wb.to(dtype).double().T + bb.double()).float()
+        assert rel_inf(buf.float().cpu(), ref.cpu()) < 2.4e-3, M2

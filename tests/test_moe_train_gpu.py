@@ -162,6 +162,9 @@ def test_three_training_steps_follow_a_torch_training_loop():
         torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0)
         opt.step()
         assert abs(logs["loss_mot_rec"] - float(loss)) < 2e-4 * max(1.0, abs(float(loss))), (it, logs, float(loss))
+        # the reference logs the unscaled load-balancing sum and adds it unscaled (ddpm_trainer.py:217-222)
+        assert logs["loss_moe"] > 0 and abs(logs["loss_total"] - (logs["loss_mot_rec"] + logs["loss_moe"])) < 1e-6
+        assert abs(logs["loss_moe_scaled"] - 0.01 * logs["loss_moe"]) < 1e-9
     new = tr.state_dict(PREFIX)
     # Adam divides by sqrt(v): an entry whose gradient is at the rounding level moves by +-lr whatever its value, so single
     # entries are ill-conditioned; the update VECTOR is compared in the L2 sense, tensor by tensor

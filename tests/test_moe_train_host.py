@@ -76,3 +76,13 @@ def test_gradient_all_reduce_is_the_mean_over_ranks_gloo():
 def test_training_step_refuses_cpu():
     with pytest.raises(Exception):
         pkg("moe_train").MoEFFNTrainer(64, 64, 4, 64, device="cpu")
+
+
+def test_logged_losses_follow_the_reference_trainer():
+    """ddpm_trainer.py:217-222 logs loss_moe = the unscaled get_moe_loss (gaussian_diffusion.py:985) and
+    loss_total = loss_mot_rec + loss_moe; the 0.01 of get_total_moe_loss (transformer.py:265-270) is not on that path."""
+    logs = pkg("moe_train").loss_logs(torch.tensor(0.25), torch.tensor(3.0), moe_coef=0.01)
+    assert list(logs)[:3] == ["loss_mot_rec", "loss_moe", "loss_total"]  # backward_G's OrderedDict
+    assert logs["loss_mot_rec"] == 0.25 and logs["loss_moe"] == 3.0 and logs["loss_total"] == 3.25
+    assert abs(logs["loss_moe_scaled"] - 0.03) < 1e-12
+    assert all(isinstance(v, float) for v in logs.values())

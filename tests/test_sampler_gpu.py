@@ -58,6 +58,59 @@ def test_ddim_loop_matches_reference(eta):
     assert rel_inf(y.cpu(), g[f"ddim{eta}/final"]) < 2e-2
 
 
+def test_free_running_clipped_ddim_loop_is_exact_until_a_one_sided_clamp():
+    """the free-running default loop (clip_denoised=True) is gated at 2e-2 above because ONE element whose
+    unclamped pred_xstart lies within the forward's error of +-1 may be clamped by one implementation only, after which that
+    SAMPLE's trajectory legitimately differs (eps is re-derived from the clamped value with a gain of ~1e2).  Here the reason
+    is checked per sample and per step: both loops run freely from the same x_T and noises; for every sample, every step
+    BEFORE the first step at which the oracle sees an element within `band` of the clamp must agree at 1e-3, the steps behind
+    it are reported (and bounded by the loose gate), and samples never interact."""
+    import os
+    import sys
+    from conftest import ROOT, golden_state
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import denoiser_ref as R
+    import diffusion_ref as DR
+    g, meta, m, diff, noises, kw = _setup()
+    steps = meta["steps_ddim"]
+    d = diff(steps)
+    kw2 = {k: kw[k] for k in ("xf_proj", "xf_out", "length")}
+    ns = noises("ddim.0.5", steps)
+    traj = {}
+    d.ddim_sample_loop(m, tuple(g["x_T"].shape), noise=g["x_T"].cuda(), model_kwargs=kw2, eta=0.5, step_noise=ns,
+                       callback=lambda i, t, x: traj.__setitem__(i, x.clone().cpu()))
+    sd, eph, proj, mcfg = golden_state(meta)
+    tb = DR.Tables(DR.linear_betas(steps))
+    x = g["x_T"].clone()
+    B = x.shape[0]
+    band = 2e-3
+    first_event = [None] * B     # per sample: first step with an element inside the band
+    exact, loose, worst_exact, worst_loose = 0, 0, 0.0, 0.0
+    for i in range(steps):
+        t = steps - 1 - i
+        tt = torch.full((B,), t, dtype=torch.int64)
+        with torch.no_grad():
+            eps = R.denoiser_forward(sd, mcfg, x, tt, g["length"], g["xf_proj"], g["xf_out"], eph, proj)
+        nxt, _ = DR.ddim_step(tb, t, x, eps, ns[i], 0.5, clip=True)
+        _, x0u = DR.ddim_step(tb, t, x, eps, ns[i], 0.5, clip=False)
+        for b in range(B):
+            if first_event[b] is None and bool(((x0u[b].abs() - 1.0).abs() < band).any()):
+                first_event[b] = i
+            e = float((traj[i][b] - nxt[b]).abs().max() / nxt.abs().max())
+            if first_event[b] is None:
+                exact += 1
+                worst_exact = max(worst_exact, e)
+                assert e < 1e-3, (i, b, e)
+            else:
+                loose += 1
+                worst_loose = max(worst_loose, e)
+        x = nxt
+    print(f"free-running clipped DDIM: {exact} (sample, step) pairs before any in-band element agree at 1e-3 (worst {worst_exact:.1e}); "
+          f"{loose} pairs behind one (first in-band step per sample: {first_event}), worst {worst_loose:.1e}")
+    assert worst_loose < 2e-2
+    assert exact > 0
+
+
 def test_step_kernels_match_oracle():
     """mdm_cfg_posterior_step / mdm_ddim_step against the oracle's step arithmetic on identical inputs."""
     import ctypes as C

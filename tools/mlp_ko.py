@@ -1,12 +1,15 @@
 """Knock-out timings of the streamed-weight fused MLP (csrc/mlp_stream.hip): the kernel with one ingredient removed per
-variant (knobs 41..46: wrong results, timing only), alternated with the real kernel in one process after a warm-up."""
+variant (knobs 41..46: wrong results, timing only), alternated with the real kernel in one process after a warm-up.
+Runs on the DIAGNOSTIC library (python motiondiffusion-moe_amd/build.py --diag): the product library refuses those knobs."""
 import importlib
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MDM_LIB", os.path.join(ROOT, "motiondiffusion-moe_amd", "libmdm_hip_diag.so"))
 ops = importlib.import_module("motiondiffusion-moe_amd.ops")
 L = importlib.import_module("motiondiffusion-moe_amd._lib")
 
@@ -48,7 +51,7 @@ def main():
         rs = torch.rand(M, device=dev)
 
         def run(v):
-            L.lib().mdm_set_gemm_variant(v)
+            L.check(L.lib().mdm_set_gemm_variant(v))
             if only16:
                 ops.fused_mlp(x16, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out16=out16, wstream=ws, only16=True)
             else:

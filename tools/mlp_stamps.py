@@ -1,12 +1,16 @@
 """Where a tile of the streamed-weight fused MLP spends its cycles: the diagnostic build (knob 49) sums s_memtime
-differences per phase in wave 0 of every workgroup (csrc/mlp_stream.hip, XSTAMP).  Shares, not run time."""
+differences per phase in wave 0 of every workgroup (csrc/mlp_stream.hip, XSTAMP).  Shares, not run time.
+Runs on the DIAGNOSTIC library (python motiondiffusion-moe_amd/build.py --diag): the product library has no stamped build."""
+import ctypes
 import importlib
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MDM_LIB", os.path.join(ROOT, "motiondiffusion-moe_amd", "libmdm_hip_diag.so"))
 ops = importlib.import_module("motiondiffusion-moe_amd.ops")
 L = importlib.import_module("motiondiffusion-moe_amd._lib")
 NAMES = ["tile lookup", "X tile -> LDS, ring fill, barrier", "phase 1 (X . W1)", "GELU", "hidden image: barriers + writes",
@@ -29,15 +33,13 @@ def main():
         gather = torch.randint(0, S, (M,), device=dev, dtype=torch.int32)
         goff = (torch.arange(G + 1, dtype=torch.int64) * M // G).to(torch.int32).to(dev)
         rs = torch.rand(M, device=dev)
-        st = torch.zeros(8, dtype=torch.int64, device=dev)
-        fake_r2 = st.view(torch.float32).reshape(1, 16)  # the diagnostic build takes the counters through the R2 pointer
+        st = torch.zeros(8, dtype=torch.int64, device=dev)  # the stamped build's counters: a buffer of their own
+        assert L.lib().mdm_diag_build() == 1, "build the diagnostic library first: python motiondiffusion-moe_amd/build.py --diag"
+        L.check(L.lib().mdm_diag_mlp_counters(ctypes.c_void_p(st.data_ptr())))
 
-        def run(v, r2=None):
-            L.lib().mdm_set_gemm_variant(v)
-            if r2 is None:
-                ops.fused_mlp(x16, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out16=out16, wstream=ws, only16=True)
-            else:  # the stamped build writes 16-bit outputs only as well (it takes its counters through R2 and ignores C)
-                ops.fused_mlp(x16, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out16=out16, wstream=ws, r2=r2, only16=True)
+        def run(v):
+            L.check(L.lib().mdm_set_gemm_variant(v))
+            ops.fused_mlp(x16, pw1, b1, pw2, b2, gather=gather, goff=goff, rowscale=rs, rows=M, out16=out16, wstream=ws, only16=True)
             L.lib().mdm_set_gemm_variant(0)
 
         for _ in range(50):
@@ -45,8 +47,9 @@ def main():
         st.zero_()
         n = 10
         for _ in range(n):
-            run(49, fake_r2)
+            run(49)
         torch.cuda.synchronize()
+        L.lib().mdm_diag_mlp_counters(None)
         v = st.cpu().tolist()
         tiles = v[7] / n
         tot = sum(v[:7])
