@@ -12,12 +12,17 @@
 //   * 2-stage ring (32 KiB per stage at BM = 128: two workgroups per CU), counted vmcnt + raw barrier, swapped MFMA operands,
 //     epilogue staged through LDS and written as whole rows, row gather + grouped mode for the expert GEMMs.
 // Results differ from gemm.hip's only by accumulation order (tests/test_gemm_gpu.py compares both with fp64).
+// ACT_HEADNORM (the q | k | v projection in front of csrc/perf_attn3.hip): a 128-column tile IS one attention head of one of
+// q / k / v, so the row-store loop -- 32 lanes hold a row of the staged tile -- applies the shared LayerNorm over head_dim and
+// the L2 normalisation of q and k (fast_attention.py:44-55) and writes the rows as bf16 hi / lo planes: the head_norm launch,
+// its fp32 round trip and the eight-fold re-splitting of the rows in the attention core are gone.
 #include "gemm.h"
 
 namespace mdm {
 namespace {
 
-constexpr int BN3 = 128, NT3 = 256;
+// tile: BM x BN outputs, waves as 2 (M) x BN / 64 (N), each wave BM / 2 rows x 64 columns: 128-column tiles run 4 waves (two
+// workgroups per CU), 256-column tiles 8 waves (one per CU, 3-stage ring: a third fewer operand bytes per output)
 
 typedef __bf16 frag3_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_3 __attribute__((ext_vector_type(4)));
@@ -31,16 +36,18 @@ __device__ __forceinline__ void wait_vm3() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int NSTAGE, int ACT>
-__global__ __launch_bounds__(NT3, 2) void gemm_x3_kernel(const GemmArgs g) {
+template <int BM, int BN3, int NSTAGE, int ACT>
+__global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
+  constexpr int NWN = BN3 / 64, NW = 2 * NWN, NT3 = 64 * NW;
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
   constexpr int TILE_A = BM * 128;              // fp32 [BM][32 k]: 128-B rows, 8 rows per 1-KiB piece
   constexpr int TILE_W = BN3 * 64;              // one bf16 plane [128][32 k]: 64-B rows, 16 rows per piece
   constexpr int STAGE_B = TILE_A + 2 * TILE_W;  // A, W hi, W lo
-  constexpr int PPA = BM / 8 / 4, PPW = BN3 / 16 / 4;
+  constexpr int PPA = BM / 8 / NW, PPW = BN3 / 16 / NW;
+  static_assert(PPA >= 1 && PPW >= 1, "every wave stages at least one piece of each operand");
   constexpr int MI = BM / 32;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / NWN, wn = wid % NWN;
   const int ntn = (g.N + BN3 - 1) / BN3;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int nt = tile % ntn, mt = tile / ntn;
@@ -207,17 +214,45 @@ __global__ __launch_bounds__(NT3, 2) void gemm_x3_kernel(const GemmArgs g) {
         v[r] = x * (cv[j][r] * rs[i]);
       }
       const int chunk = wn * 16 + j * 4 + fq;
-      *(f32x4*)(stg + ml * 128 + ((chunk ^ (ml & 31)) << 2)) = v;
+      *(f32x4*)(stg + ml * BN3 + ((chunk ^ (ml & 31)) << 2)) = v;
     }
   }
   __syncthreads();
-  const int cl = tid & 31, n = nt * BN3 + 4 * cl;
+  constexpr int TPR = BN3 / 4;  // threads per staged row (4 columns each); NT3 / TPR = 8 rows per sweep
+  const int cl = tid % TPR, n = nt * BN3 + 4 * cl;
   const bool vec = ((g.ldc & 3) == 0) && (!R1 || (g.ldr1 & 3) == 0) && (!R2 || (g.ldr2 & 3) == 0) && n + 4 <= g.N;
+  if constexpr (ACT == ACT_HEADNORM) {
+    // the tile's 128 columns are one head: LayerNorm over them (weights by position inside the head), q and k tiles
+    // L2-normalised, rows out as bf16 hi / lo planes.  Arithmetic as rowwise.hip head_norm_kernel<32> (32 lanes x 4 columns).
+    const f32x4 ww = *(const f32x4*)(g.hn_w + 4 * (cl & 31)), bb = *(const f32x4*)(g.hn_b + 4 * (cl & 31));
+    const bool l2 = nt * (BN3 / 128) + (cl >> 5) < g.hn_l2_tiles;  // the head slice of these 32 lanes
+#pragma unroll
+    for (int k = 0; k < BM / 8; ++k) {
+      const int ml = tid / TPR + 8 * k, m = row0 + ml;  // (uniform per half wave: the reductions stay inside the 32 lanes)
+      f32x4 v = *(const f32x4*)(stg + ml * BN3 + ((cl ^ (ml & 31)) << 2));
+      const float mean = group_sum<32>(v[0] + v[1] + v[2] + v[3]) / 128.f;
+      const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+      const float rstd = rsqrtf(group_sum<32>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) / 128.f + 1e-5f);
+      v = (f32x4){d[0] * rstd * ww[0] + bb[0], d[1] * rstd * ww[1] + bb[1], d[2] * rstd * ww[2] + bb[2], d[3] * rstd * ww[3] + bb[3]};
+      if (l2) {
+        const float nrm = sqrtf(group_sum<32>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+        const float inv = 1.f / fmaxf(nrm, 1e-12f);
+        v *= inv;
+      }
+      if (m >= row_end) continue;
+      uint32_t h0, h1, l0, l1;
+      split_bf16(v[0], v[1], h0, l0);
+      split_bf16(v[2], v[3], h1, l1);
+      *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(h0, h1);
+      *(uint2*)(g.C16_lo + (int64_t)m * g.ldc + n) = make_uint2(l0, l1);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < BM / 8; ++k) {
-    const int ml = (tid >> 5) + 8 * k, m = row0 + ml;
+    const int ml = tid / TPR + 8 * k, m = row0 + ml;
     if (m >= row_end || n >= g.N) continue;
-    f32x4 v = *(const f32x4*)(stg + ml * 128 + ((cl ^ (ml & 31)) << 2));
+    f32x4 v = *(const f32x4*)(stg + ml * BN3 + ((cl ^ (ml & 31)) << 2));
     const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
     if (vec) {
       if (R1) {
@@ -242,28 +277,30 @@ __global__ __launch_bounds__(NT3, 2) void gemm_x3_kernel(const GemmArgs g) {
   }
 }
 
-template <int BM, int NS, int ACT>
+template <int BM, int BN, int NS, int ACT>
 int launch3_act(const GemmArgs& a, hipStream_t stream) {
-  constexpr int ring = NS * (BM * 128 + 2 * BN3 * 64), stgb = BM * 128 * 4;
+  constexpr int ring = NS * (BM * 128 + 2 * BN * 64), stgb = BM * BN * 4;
   constexpr int smem = ring > stgb ? ring : stgb;
+  static_assert(smem <= 160 * 1024, "LDS");
   static DevOnce attr;
   if (smem > 65536 && !attr) {
-    if (hipFuncSetAttribute((const void*)gemm_x3_kernel<BM, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_x3_kernel<BM, BN, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr = true;
   }
   const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
-  const int tn = (a.N + BN3 - 1) / BN3;
-  hipLaunchKernelGGL((gemm_x3_kernel<BM, NS, ACT>), dim3((unsigned)(tm * tn)), dim3(NT3), smem, stream, a);
+  const int tn = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, NS, ACT>), dim3((unsigned)(tm * tn)), dim3(2 * BN), smem, stream, a);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
 }
-template <int BM, int NS>
+template <int BM, int BN, int NS>
 int launch3(const GemmArgs& a, hipStream_t stream) {
   switch (a.act) {
-    case ACT_NONE: return launch3_act<BM, NS, ACT_NONE>(a, stream);
-    case ACT_GELU: return launch3_act<BM, NS, ACT_GELU>(a, stream);
-    case ACT_SILU: return launch3_act<BM, NS, ACT_SILU>(a, stream);
+    case ACT_NONE: return launch3_act<BM, BN, NS, ACT_NONE>(a, stream);
+    case ACT_GELU: return launch3_act<BM, BN, NS, ACT_GELU>(a, stream);
+    case ACT_SILU: return launch3_act<BM, BN, NS, ACT_SILU>(a, stream);
+    case ACT_HEADNORM: return launch3_act<BM, BN, NS, ACT_HEADNORM>(a, stream);
     default: return MDM_ERR_UNSUPPORTED;
   }
 }
@@ -276,18 +313,25 @@ bool gemm_x3_dma_eligible(const GemmArgs& a) {
   return a.precision == 3 && a.A.kind == OP_F32_ROW && a.W.kind == OP_BF16_ROW && a.W.p_lo && a.batch == 1 && a.A.rpg == 0 &&
          a.K >= 32 && (a.K % 32) == 0 && (a.A.ld % 4) == 0 && (a.W.ld % 8) == 0 && (a.W.bs1 % 8) == 0 &&
          ((((uintptr_t)a.A.p) | ((uintptr_t)a.W.p) | ((uintptr_t)a.W.p_lo)) & 15) == 0 &&
-         (a.act == ACT_NONE || a.act == ACT_GELU || a.act == ACT_SILU) && a.M >= 1;
+         (a.act == ACT_NONE || a.act == ACT_GELU || a.act == ACT_SILU ||
+          (a.act == ACT_HEADNORM && a.N % 128 == 0 && a.C16 && a.C16_lo && a.hn_w && a.hn_b && !a.C && !a.R1 && !a.R2 && !a.goff &&
+           (a.ldc % 4) == 0 && ((((uintptr_t)a.C16) | ((uintptr_t)a.C16_lo)) & 7) == 0 && ((((uintptr_t)a.hn_w) | ((uintptr_t)a.hn_b)) & 15) == 0)) &&
+         a.M >= 1;
 }
 
 int gemm_x3_dma(const GemmArgs& a, hipStream_t stream) {
   if (!gemm_x3_dma_eligible(a)) return MDM_ERR_UNSUPPORTED;
   if (!a.C && !a.C16) return MDM_ERR_ARG;
-  const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + BN3 - 1) / BN3);
+  const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const bool small = !a.goff && (tiles128 <= 256 || a.M <= 64);
-  if (g_bf16_variant == 37) return launch3<128, 3>(a, stream);  // A/B knobs: ring depth at the 128-row tile
-  if (g_bf16_variant == 38) return launch3<128, 4>(a, stream);
-  if (g_bf16_variant == 39) return launch3<64, 3>(a, stream);
-  return small ? launch3<64, 3>(a, stream) : launch3<128, 2>(a, stream);
+  if (g_bf16_variant == 37) return launch3<128, 128, 3>(a, stream);  // A/B knobs: ring depth at the 128-row tile
+  if (g_bf16_variant == 38) return launch3<128, 128, 4>(a, stream);
+  if (g_bf16_variant == 39) return launch3<64, 128, 3>(a, stream);
+  // 256-column tiles (8 waves, 3-stage ring, one workgroup per CU): knob 53 / 54 force the 128- / 64-row form wherever N allows
+  const bool wide_ok = a.N % 256 == 0;
+  if (wide_ok && g_bf16_variant == 53) return launch3<128, 256, 3>(a, stream);
+  if (wide_ok && g_bf16_variant == 54) return launch3<64, 256, 3>(a, stream);
+  return small ? launch3<64, 128, 3>(a, stream) : launch3<128, 128, 2>(a, stream);
 }
 
 }  // namespace mdm

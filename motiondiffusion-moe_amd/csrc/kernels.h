@@ -53,6 +53,12 @@ bool perf_attn256_supported(int dh, int S);
 int64_t perf_attn256_scratch_bytes(int B, int H, int S);
 int perf_attn256(const void* qkv, int h16, const uint16_t* PT, int ldp, const float* hn_w, const float* hn_b, const int* len,
                  int B, int S, int H, uint16_t* out, void* scratch, hipStream_t s);
+// perf_attn3.hip: the same core in the fp32-grade (bf16x3) arithmetic, head_dim 128: xh / xl = hi / lo planes [B S, 3 D] of the
+// q | k | v rows after LayerNorm(dh) and the L2 normalisation of q, k (the projection GEMM's ACT_HEADNORM epilogue), ph / pl =
+// planes of P^T [128][ldp]; out fp32 [B S, D]
+bool perf_attn3_supported(int dh, int S);
+int perf_attn3(const uint16_t* xh, const uint16_t* xl, const uint16_t* ph, const uint16_t* pl, int ldp, const float* hn_w,
+               const float* hn_b, const int* len, int B, int S, int H, int dh, float* out, hipStream_t s);
 // ntok (optional, int32 [rows / rows_per_b]): row r attends to its first ntok[r / rows_per_b] columns only, the rest get 0
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s, const int32_t* ntok = nullptr, int64_t rows_per_b = 1);
 // fused text cross-attention cores (xattn.hip), head_dim 128

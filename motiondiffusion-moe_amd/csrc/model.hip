@@ -239,13 +239,31 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
   // workgroup per (batch, head) multiplies its sample's rows with its head's 384 weight rows; k and v never leave the CU).
   // Knob 50: the projection as its own GEMM launch.
   const bool qkv_in = fused && !fused256 && xn.bf && g_bf16_variant != 50 && perf_attn_qkv_supported(dh, c.S, H);
+  // fp32-grade modes, head_dim 128: the projection's epilogue applies LN(dh) / L2 and writes bf16 hi | lo planes, ONE launch
+  // (csrc/perf_attn3.hip) does features -> KV state -> num / den -> LN on bf16x3 products.  Knob 52: the five-launch chain.
+  const bool fused3 = !c.bf && c.prec == 3 && !xn.bf && g_bf16_variant != 52 && perf_attn3_supported(dh, c.S) && D % 32 == 0 &&
+                      p.qkv.lo && p.feat.lo && (c.M * 3 * D) % 8 == 0;
+  if (fused3) {
+    uint16_t* const xh = (uint16_t*)w.qkv;
+    uint16_t* const xl = xh + c.M * 3 * D;  // the two 16-bit planes fill the fp32 [M, 3 D] buffer exactly
+    GemmArgs g = gd(c);
+    g.A = op_f32((const float*)xn.p, D);
+    g.W = packed(p.qkv);
+    g.M = (int)c.M, g.N = 3 * D, g.K = D;
+    g.bias = p.qkv_b, g.alpha = 0.1f;
+    g.act = ACT_HEADNORM, g.hn_w = p.hn_w, g.hn_b = p.hn_b, g.hn_l2_tiles = 2 * H;
+    g.C16 = xh, g.C16_lo = xl, g.ldc = 3 * D;
+    MDM_TRY(gemm(g, c.s));
+    MDM_TRY(perf_attn3(xh, xl, p.feat.hi, p.feat.lo, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, w.t4, c.s));
+  }
   // q|k|v = 0.1 * (xn W^T + b)                                   (:145-157); bf16 when the fused attention core reads it
-  if (!qkv_in) {
+  if (!qkv_in && !fused3) {
     LinOpts o;
     o.alpha = 0.1f;
     MDM_TRY(linear(c, xn, c.M, D, p.qkv, p.qkv_b, 3 * D, fused ? nullptr : w.qkv, fused ? (uint16_t*)w.qkv : nullptr, o));
   }
-  if (qkv_in) {
+  if (fused3) {
+  } else if (qkv_in) {
     MDM_TRY(perf_attn_qkv((const uint16_t*)xn.p, p.qkv.hi, (int)p.qkv.ld, p.qkv_b, 0.1f, (uint16_t*)w.qkv, c.h16, p.feat.hi,
                           (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, (uint16_t*)w.t4, c.s));
   } else if (fused256) {

@@ -304,3 +304,33 @@ def test_named_block_entry_points(precision):
         err = rel_inf(out.cpu(), ref)
         print(f"performer {slot} precision {precision}: {err:.2e}")
         assert err < TOL[precision], (slot, err)
+
+
+@pytest.mark.parametrize("precision", [3, 4])
+@pytest.mark.parametrize("B,S", [(2, 98), (3, 196), (2, 40), (1, 6), (2, 224)])
+def test_fp32_grade_attention_core_in_one_launch(B, S, precision):
+    """csrc/perf_attn3.hip (+ the ACT_HEADNORM epilogue of the q | k | v projection, csrc/gemm3.hip): the Performer core of
+    the fp32-grade modes as ONE launch on bf16x3 products against (a) the five-launch chain it replaces (knob 52: head_norm,
+    feature GEMM, KV-state GEMM, numerator GEMM, den_ln) on identical inputs and (b) the oracle's block; ragged lengths (a
+    masked tail, a length-1 sample), frame counts that are not multiples of the 16-frame tile or the 32-frame chunk, one
+    chunk (S <= 32) and the largest supported S."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, 6, precision)
+    L = pkg("_lib")
+    length = length.clone()
+    if B >= 2:
+        length[1] = max(1, S - 13)
+    if B >= 3:
+        length[2] = 1
+    mask = R.src_mask(S, length)
+    with torch.no_grad():
+        ref = R.dual_self_attention(h, emb, mask, sd, pre + ".dual_self_attn", H, eph, proj, "low.0")
+    out = _run_block(m, L.BLOCK_DUAL, h, sc, length, xf)
+    L.lib().mdm_set_gemm_variant(52)
+    try:
+        chain = _run_block(m, L.BLOCK_DUAL, h, sc, length, xf)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    e_ref, e_chain = rel_inf(out, ref), rel_inf(out, chain)
+    print(f"B={B} S={S} precision={precision}: fused vs oracle {e_ref:.2e}, chain vs oracle {rel_inf(chain, ref):.2e}, fused vs chain {e_chain:.2e}")
+    assert torch.isfinite(out).all()
+    assert e_ref < 1e-3 and e_chain < 2e-4
