@@ -28,7 +28,10 @@ enum { MDM_ACT_NONE = 0, MDM_ACT_GELU = 1, MDM_ACT_SILU = 2, MDM_ACT_FEAT = 3,
        /* fp32-grade kernel only (precision 3, N % 128 == 0): every 128-column slice of a row is one attention head --
         * LayerNorm over the slice with hn_w / hn_b (eps 1e-5), L2-normalised when the slice index is < hn_l2_tiles
         * (fast_attention.py:44-55 on the q | k | v projection), written as bf16 hi / lo planes C16 / C16_lo */
-       MDM_ACT_HEADNORM = 4 };
+       MDM_ACT_HEADNORM = 4,
+       /* the same kernel: softmax over every 128-column slice (the head_dim softmax of the linear cross-attention's query,
+        * fast_attention.py:248), written as bf16 hi / lo planes C16 / C16_lo */
+       MDM_ACT_HEADSOFTMAX = 5 };
 /* 16-bit operand / storage format of the single-pass MFMA kernels: bf16, or IEEE fp16 (same MFMA rate on gfx950, 8x finer
  * rounding, |x| <= 65504: used where the value range is known). */
 enum { MDM_H16_BF16 = 1, MDM_H16_F16 = 2 };
@@ -94,7 +97,8 @@ typedef struct MdmGemmDesc {
    * [kgoff[z], kgoff[z+1]) -- the routed rows of expert group z -- instead of [0, K); an empty range writes epilogue(0) */
   const int32_t* kgoff;
   /* MDM_ACT_HEADNORM: LayerNorm weight / bias over head_dim = 128, number of leading 128-column slices that are also
-   * L2-normalised (2 H for q | k | v), and the lo plane of the output (C16 = hi plane; hi + lo = the fp32 value to ~2^-17) */
+   * L2-normalised (2 H for q | k | v), and the lo plane of the output (C16 = hi plane; hi + lo = the fp32 value to ~2^-17).
+   * C16_lo with MDM_ACT_NONE / HEADSOFTMAX on the fp32-grade kernel: the result leaves as bf16 hi / lo planes (C must be NULL) */
   const float* hn_w;
   const float* hn_b;
   uint16_t* C16_lo;

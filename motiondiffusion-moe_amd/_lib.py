@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MDM_LIB") or os.path.join(_HERE, "libmdm_hip.so")  # 
 _lib = None
 
 OP_F32_ROW, OP_F32_KSTRIDE, OP_BF16_ROW, OP_FP8_ROW = 0, 1, 2, 3
-ACT_NONE, ACT_GELU, ACT_SILU, ACT_FEAT, ACT_HEADNORM = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_FEAT, ACT_HEADNORM, ACT_HEADSOFTMAX = 0, 1, 2, 3, 4, 5
 H16_BF16, H16_F16 = 1, 2  # MDM_H16_*
 PREC_BF16, PREC_F16, PREC_X3, PREC_MIXED, PREC_FP8 = 1, 2, 3, 4, 5  # MDM_PREC_*
 PRECISIONS = (PREC_BF16, PREC_F16, PREC_X3, PREC_MIXED, PREC_FP8)

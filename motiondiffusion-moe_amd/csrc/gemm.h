@@ -12,7 +12,7 @@ typedef MdmOperand Operand;
 typedef MdmGemmDesc GemmArgs;
 
 enum OperandKind { OP_F32_ROW = MDM_OP_F32_ROW, OP_F32_KSTRIDE = MDM_OP_F32_KSTRIDE, OP_BF16_ROW = MDM_OP_BF16_ROW };
-enum Act { ACT_NONE = MDM_ACT_NONE, ACT_GELU = MDM_ACT_GELU, ACT_SILU = MDM_ACT_SILU, ACT_FEAT = MDM_ACT_FEAT, ACT_HEADNORM = MDM_ACT_HEADNORM };
+enum Act { ACT_NONE = MDM_ACT_NONE, ACT_GELU = MDM_ACT_GELU, ACT_SILU = MDM_ACT_SILU, ACT_FEAT = MDM_ACT_FEAT, ACT_HEADNORM = MDM_ACT_HEADNORM, ACT_HEADSOFTMAX = MDM_ACT_HEADSOFTMAX };
 
 inline GemmArgs gemm_defaults(int precision) {
   GemmArgs g = {};

@@ -383,7 +383,8 @@ int gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.goff && (a.batch != 1 || a.ngroups <= 0)) return MDM_ERR_ARG;
   if (a.kgoff && (a.goff || a.A.kind != OP_F32_KSTRIDE || a.W.kind != OP_F32_KSTRIDE)) return MDM_ERR_ARG;
   // plain Linears of the fp32-grade mode: LDS-DMA staged bf16x3 kernel (gemm3.hip); knob 36 keeps the register-staged one
-  if ((g_bf16_variant != 36 || a.act == ACT_HEADNORM) && gemm_x3_dma_eligible(a)) return gemm_x3_dma(a, stream);
+  if ((g_bf16_variant != 36 || a.act == ACT_HEADNORM || a.act == ACT_HEADSOFTMAX || a.C16_lo) && gemm_x3_dma_eligible(a)) return gemm_x3_dma(a, stream);
+  if (a.C16_lo) return MDM_ERR_UNSUPPORTED;  // plane outputs exist on that kernel only
   const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
   const int tn = (a.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);

@@ -195,83 +195,116 @@ __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
   uint16_t* __restrict__ C16 = g.C16;
   const float* __restrict__ R1 = g.R1;
   const float* __restrict__ R2 = g.R2;
-  __syncthreads();
+  // 256 x 256 tiles stage their fp32 outputs in two passes of 128 rows (the rows of the waves with wm == pass): 128 KiB each
+  constexpr int EP = (BM * BN3 * 4 > 128 * 1024) ? 2 : 1, RP = BM / EP;
+  static_assert(EP == 1 || RP == BM / 2, "a pass = the rows of one wave row group");
   float* stg = (float*)smem;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int ml = wm * (BM / 2) + i * 16 + frow;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 v;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = g.alpha * (acc[i][j][r] + bv[j][r]);
-        if constexpr (ACT == ACT_GELU) {
-          x = gelu_erf(x);
-        } else if constexpr (ACT == ACT_SILU) {
-          x = silu(x);
-        }
-        v[r] = x * (cv[j][r] * rs[i]);
-      }
-      const int chunk = wn * 16 + j * 4 + fq;
-      *(f32x4*)(stg + ml * BN3 + ((chunk ^ (ml & 31)) << 2)) = v;
-    }
-  }
-  __syncthreads();
   constexpr int TPR = BN3 / 4;  // threads per staged row (4 columns each); NT3 / TPR = 8 rows per sweep
   const int cl = tid % TPR, n = nt * BN3 + 4 * cl;
   const bool vec = ((g.ldc & 3) == 0) && (!R1 || (g.ldr1 & 3) == 0) && (!R2 || (g.ldr2 & 3) == 0) && n + 4 <= g.N;
-  if constexpr (ACT == ACT_HEADNORM) {
-    // the tile's 128 columns are one head: LayerNorm over them (weights by position inside the head), q and k tiles
-    // L2-normalised, rows out as bf16 hi / lo planes.  Arithmetic as rowwise.hip head_norm_kernel<32> (32 lanes x 4 columns).
-    const f32x4 ww = *(const f32x4*)(g.hn_w + 4 * (cl & 31)), bb = *(const f32x4*)(g.hn_b + 4 * (cl & 31));
-    const bool l2 = nt * (BN3 / 128) + (cl >> 5) < g.hn_l2_tiles;  // the head slice of these 32 lanes
 #pragma unroll
-    for (int k = 0; k < BM / 8; ++k) {
-      const int ml = tid / TPR + 8 * k, m = row0 + ml;  // (uniform per half wave: the reductions stay inside the 32 lanes)
-      f32x4 v = *(const f32x4*)(stg + ml * BN3 + ((cl ^ (ml & 31)) << 2));
-      const float mean = group_sum<32>(v[0] + v[1] + v[2] + v[3]) / 128.f;
-      const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
-      const float rstd = rsqrtf(group_sum<32>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) / 128.f + 1e-5f);
-      v = (f32x4){d[0] * rstd * ww[0] + bb[0], d[1] * rstd * ww[1] + bb[1], d[2] * rstd * ww[2] + bb[2], d[3] * rstd * ww[3] + bb[3]};
-      if (l2) {
-        const float nrm = sqrtf(group_sum<32>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
-        const float inv = 1.f / fmaxf(nrm, 1e-12f);
-        v *= inv;
+  for (int ps = 0; ps < EP; ++ps) {
+    __syncthreads();
+    if (EP == 1 || wm == ps) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int ml = (EP == 1 ? wm * (BM / 2) : 0) + i * 16 + frow;  // row inside this pass
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = g.alpha * (acc[i][j][r] + bv[j][r]);
+            if constexpr (ACT == ACT_GELU) {
+              x = gelu_erf(x);
+            } else if constexpr (ACT == ACT_SILU) {
+              x = silu(x);
+            }
+            v[r] = x * (cv[j][r] * rs[i]);
+          }
+          const int chunk = wn * 16 + j * 4 + fq;
+          *(f32x4*)(stg + ml * BN3 + ((chunk ^ (ml & 31)) << 2)) = v;
+        }
       }
-      if (m >= row_end) continue;
-      uint32_t h0, h1, l0, l1;
-      split_bf16(v[0], v[1], h0, l0);
-      split_bf16(v[2], v[3], h1, l1);
-      *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(h0, h1);
-      *(uint2*)(g.C16_lo + (int64_t)m * g.ldc + n) = make_uint2(l0, l1);
     }
-    return;
-  }
+    __syncthreads();
+    if constexpr (ACT == ACT_HEADSOFTMAX) {
+      // softmax over each 128-column slice (one head), arithmetic as rowwise.hip head_softmax_kernel<32>; rows out as planes
 #pragma unroll
-  for (int k = 0; k < BM / 8; ++k) {
-    const int ml = tid / TPR + 8 * k, m = row0 + ml;
-    if (m >= row_end || n >= g.N) continue;
-    f32x4 v = *(const f32x4*)(stg + ml * BN3 + ((cl ^ (ml & 31)) << 2));
-    const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
-    if (vec) {
-      if (R1) {
-        const f32x4 q = *(const f32x4*)(R1 + mr * g.ldr1 + n);
-        v[0] += g.r1_scale * q[0], v[1] += g.r1_scale * q[1], v[2] += g.r1_scale * q[2], v[3] += g.r1_scale * q[3];
+      for (int k = 0; k < RP / 8; ++k) {
+        const int ml = tid / TPR + 8 * k, m = row0 + ps * RP + ml;
+        f32x4 v = *(const f32x4*)(stg + ml * BN3 + ((cl ^ (ml & 31)) << 2));
+        const float mx = group_max<32>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        v = (f32x4){expf(v[0] - mx), expf(v[1] - mx), expf(v[2] - mx), expf(v[3] - mx)};
+        const float sm = group_sum<32>(v[0] + v[1] + v[2] + v[3]);
+        v = (f32x4){v[0] / sm, v[1] / sm, v[2] / sm, v[3] / sm};
+        if (m >= row_end) continue;
+        uint32_t h0, h1, l0, l1;
+        split_bf16(v[0], v[1], h0, l0);
+        split_bf16(v[2], v[3], h1, l1);
+        *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(h0, h1);
+        *(uint2*)(g.C16_lo + (int64_t)m * g.ldc + n) = make_uint2(l0, l1);
       }
-      if (R2) {
-        const f32x4 q = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
-        v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
+    } else if constexpr (ACT == ACT_HEADNORM) {
+      // a 128-column slice of the tile is one head: LayerNorm over it (weights by position inside the head), q and k slices
+      // L2-normalised, rows out as bf16 hi / lo planes.  Arithmetic as rowwise.hip head_norm_kernel<32> (32 lanes x 4 columns).
+      const f32x4 ww = *(const f32x4*)(g.hn_w + 4 * (cl & 31)), bb = *(const f32x4*)(g.hn_b + 4 * (cl & 31));
+      const bool l2 = nt * (BN3 / 128) + (cl >> 5) < g.hn_l2_tiles;  // the head slice of these 32 lanes
+#pragma unroll
+      for (int k = 0; k < RP / 8; ++k) {
+        const int ml = tid / TPR + 8 * k, m = row0 + ps * RP + ml;  // (uniform per half wave: the reductions stay inside the 32 lanes)
+        f32x4 v = *(const f32x4*)(stg + ml * BN3 + ((cl ^ (ml & 31)) << 2));
+        const float mean = group_sum<32>(v[0] + v[1] + v[2] + v[3]) / 128.f;
+        const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+        const float rstd = rsqrtf(group_sum<32>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) / 128.f + 1e-5f);
+        v = (f32x4){d[0] * rstd * ww[0] + bb[0], d[1] * rstd * ww[1] + bb[1], d[2] * rstd * ww[2] + bb[2], d[3] * rstd * ww[3] + bb[3]};
+        if (l2) {
+          const float nrm = sqrtf(group_sum<32>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+          const float inv = 1.f / fmaxf(nrm, 1e-12f);
+          v *= inv;
+        }
+        if (m >= row_end) continue;
+        uint32_t h0, h1, l0, l1;
+        split_bf16(v[0], v[1], h0, l0);
+        split_bf16(v[2], v[3], h1, l1);
+        *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(h0, h1);
+        *(uint2*)(g.C16_lo + (int64_t)m * g.ldc + n) = make_uint2(l0, l1);
       }
-      if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;
-      if (C16) *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(pack_h16(g.h16, v[0], v[1]), pack_h16(g.h16, v[2], v[3]));
     } else {
-      for (int r = 0; r < 4 && n + r < g.N; ++r) {
-        float x = v[r];
-        if (R1) x += g.r1_scale * R1[mr * g.ldr1 + n + r];
-        if (R2) x += R2[(int64_t)m * g.ldr2 + n + r];
-        if (C) C[(int64_t)m * g.ldc + n + r] = x;
-        if (C16) C16[(int64_t)m * g.ldc + n + r] = (uint16_t)(pack_h16(g.h16, x, 0.f) & 0xffff);
+#pragma unroll
+      for (int k = 0; k < RP / 8; ++k) {
+        const int ml = tid / TPR + 8 * k, m = row0 + ps * RP + ml;
+        if (m >= row_end || n >= g.N) continue;
+        f32x4 v = *(const f32x4*)(stg + ml * BN3 + ((cl ^ (ml & 31)) << 2));
+        const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
+        if (vec) {
+          if (R1) {
+            const f32x4 q = *(const f32x4*)(R1 + mr * g.ldr1 + n);
+            v[0] += g.r1_scale * q[0], v[1] += g.r1_scale * q[1], v[2] += g.r1_scale * q[2], v[3] += g.r1_scale * q[3];
+          }
+          if (R2) {
+            const f32x4 q = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
+            v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
+          }
+          if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;
+          if (g.C16_lo) {  // bf16 hi / lo planes (the operand format of the fp32-grade attention cores)
+            uint32_t h0, h1, l0, l1;
+            split_bf16(v[0], v[1], h0, l0);
+            split_bf16(v[2], v[3], h1, l1);
+            *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(h0, h1);
+            *(uint2*)(g.C16_lo + (int64_t)m * g.ldc + n) = make_uint2(l0, l1);
+          } else if (C16) {
+            *(uint2*)(C16 + (int64_t)m * g.ldc + n) = make_uint2(pack_h16(g.h16, v[0], v[1]), pack_h16(g.h16, v[2], v[3]));
+          }
+        } else {
+          for (int r = 0; r < 4 && n + r < g.N; ++r) {
+            float x = v[r];
+            if (R1) x += g.r1_scale * R1[mr * g.ldr1 + n + r];
+            if (R2) x += R2[(int64_t)m * g.ldr2 + n + r];
+            if (C) C[(int64_t)m * g.ldc + n + r] = x;
+            if (C16) C16[(int64_t)m * g.ldc + n + r] = (uint16_t)(pack_h16(g.h16, x, 0.f) & 0xffff);
+          }
+        }
       }
     }
   }
@@ -279,7 +312,7 @@ __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
 
 template <int BM, int BN, int NS, int ACT>
 int launch3_act(const GemmArgs& a, hipStream_t stream) {
-  constexpr int ring = NS * (BM * 128 + 2 * BN * 64), stgb = BM * BN * 4;
+  constexpr int ring = NS * (BM * 128 + 2 * BN * 64), stgb = (BM * BN * 4 > 128 * 1024) ? BM * BN * 2 : BM * BN * 4;
   constexpr int smem = ring > stgb ? ring : stgb;
   static_assert(smem <= 160 * 1024, "LDS");
   static DevOnce attr;
@@ -301,6 +334,7 @@ int launch3(const GemmArgs& a, hipStream_t stream) {
     case ACT_GELU: return launch3_act<BM, BN, NS, ACT_GELU>(a, stream);
     case ACT_SILU: return launch3_act<BM, BN, NS, ACT_SILU>(a, stream);
     case ACT_HEADNORM: return launch3_act<BM, BN, NS, ACT_HEADNORM>(a, stream);
+    case ACT_HEADSOFTMAX: return launch3_act<BM, BN, NS, ACT_HEADSOFTMAX>(a, stream);
     default: return MDM_ERR_UNSUPPORTED;
   }
 }
@@ -310,13 +344,18 @@ int launch3(const GemmArgs& a, hipStream_t stream) {
 extern int g_bf16_variant;
 
 bool gemm_x3_dma_eligible(const GemmArgs& a) {
-  return a.precision == 3 && a.A.kind == OP_F32_ROW && a.W.kind == OP_BF16_ROW && a.W.p_lo && a.batch == 1 && a.A.rpg == 0 &&
-         a.K >= 32 && (a.K % 32) == 0 && (a.A.ld % 4) == 0 && (a.W.ld % 8) == 0 && (a.W.bs1 % 8) == 0 &&
-         ((((uintptr_t)a.A.p) | ((uintptr_t)a.W.p) | ((uintptr_t)a.W.p_lo)) & 15) == 0 &&
-         (a.act == ACT_NONE || a.act == ACT_GELU || a.act == ACT_SILU ||
-          (a.act == ACT_HEADNORM && a.N % 128 == 0 && a.C16 && a.C16_lo && a.hn_w && a.hn_b && !a.C && !a.R1 && !a.R2 && !a.goff &&
-           (a.ldc % 4) == 0 && ((((uintptr_t)a.C16) | ((uintptr_t)a.C16_lo)) & 7) == 0 && ((((uintptr_t)a.hn_w) | ((uintptr_t)a.hn_b)) & 15) == 0)) &&
-         a.M >= 1;
+  const bool base = a.precision == 3 && a.A.kind == OP_F32_ROW && a.W.kind == OP_BF16_ROW && a.W.p_lo && a.batch == 1 && a.A.rpg == 0 &&
+                    a.K >= 32 && (a.K % 32) == 0 && (a.A.ld % 4) == 0 && (a.W.ld % 8) == 0 && (a.W.bs1 % 8) == 0 &&
+                    ((((uintptr_t)a.A.p) | ((uintptr_t)a.W.p) | ((uintptr_t)a.W.p_lo)) & 15) == 0 && a.M >= 1;
+  if (!base) return false;
+  // hi / lo plane outputs: whole 128-column slices, vector stores, no fp32 copy
+  const bool planes_ok = a.C16 && a.C16_lo && !a.C && a.N % 128 == 0 && (a.ldc % 4) == 0 && (!a.R1 || (a.ldr1 & 3) == 0) &&
+                         (!a.R2 || (a.ldr2 & 3) == 0) && ((((uintptr_t)a.C16) | ((uintptr_t)a.C16_lo)) & 7) == 0;
+  if (a.C16_lo && !planes_ok) return false;
+  if (a.act == ACT_HEADNORM)
+    return planes_ok && a.hn_w && a.hn_b && !a.R1 && !a.R2 && !a.goff && ((((uintptr_t)a.hn_w) | ((uintptr_t)a.hn_b)) & 15) == 0;
+  if (a.act == ACT_HEADSOFTMAX) return planes_ok && !a.R1 && !a.R2 && !a.goff;
+  return a.act == ACT_NONE || a.act == ACT_GELU || a.act == ACT_SILU;
 }
 
 int gemm_x3_dma(const GemmArgs& a, hipStream_t stream) {
@@ -327,10 +366,6 @@ int gemm_x3_dma(const GemmArgs& a, hipStream_t stream) {
   if (g_bf16_variant == 37) return launch3<128, 128, 3>(a, stream);  // A/B knobs: ring depth at the 128-row tile
   if (g_bf16_variant == 38) return launch3<128, 128, 4>(a, stream);
   if (g_bf16_variant == 39) return launch3<64, 128, 3>(a, stream);
-  // 256-column tiles (8 waves, 3-stage ring, one workgroup per CU): knob 53 / 54 force the 128- / 64-row form wherever N allows
-  const bool wide_ok = a.N % 256 == 0;
-  if (wide_ok && g_bf16_variant == 53) return launch3<128, 256, 3>(a, stream);
-  if (wide_ok && g_bf16_variant == 54) return launch3<64, 256, 3>(a, stream);
   return small ? launch3<64, 128, 3>(a, stream) : launch3<128, 128, 2>(a, stream);
 }
 

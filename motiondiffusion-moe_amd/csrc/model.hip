@@ -408,6 +408,23 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
   bool x16o = false;
   // head_dim 128: the query projection inside the attention launch (csrc/xattn.hip lin_xattn_q; knob 51: its own GEMM launch)
   const bool q_in = fused && g_bf16_variant != 51 && D == 512 && lin_xattn_q_supported(dh, c.S, H);
+  // fp32-grade modes, head_dim 128: the head_dim softmax is the query projection's epilogue (bf16 hi | lo planes), the product with
+  // A[b, h] one launch on bf16x3 MFMAs (csrc/xattn3.hip).  Knob 56: the chain (GEMM, head_softmax, batched contraction).
+  const bool fused3 = !c.bf && c.prec == 3 && g_bf16_variant != 56 && xattn3_supported(dh, 1) && l.ca_q.lo && D % 32 == 0 &&
+                      (c.M * D) % 8 == 0;
+  if (fused3) {
+    uint16_t* const qh = (uint16_t*)w.t3;
+    uint16_t* const ql = qh + c.M * D;  // the two planes fill the fp32 [M, D] buffer exactly
+    GemmArgs g = gd(c);
+    g.A = op_f32(w.t2, D);
+    g.W = packed(l.ca_q);
+    g.M = (int)c.M, g.N = D, g.K = D;
+    g.bias = l.ca_q_b, g.act = ACT_HEADSOFTMAX;
+    g.C16 = qh, g.C16_lo = ql, g.ldc = D;
+    MDM_TRY(gemm(g, c.s));
+    MDM_TRY(lin_xattn3(qh, ql, at, c.B, c.S, H, dh, w.t4, c.s));
+    return style_apply(c, l.ca_style, w.t4, nullptr, nullptr, nullptr, sc, w.t2, x, 1.f, l.ca_gvec, out, nullptr, false);
+  }
   if (!q_in) MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
   if (q_in) {
     x16o = g_bf16_variant != 25;
@@ -584,14 +601,30 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
     o.R1 = x, o.R2 = w.t3;
     return linear(c, act_of(c, w.f1), c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, out16, o);
   }
-  {
+  // fp32-grade modes, head_dim 128: the query projection leaves as bf16 hi | lo planes, scores / softmax / PV are one launch on
+  // bf16x3 MFMAs (csrc/xattn3.hip).  Knob 56: the chain (two batched contractions around a row softmax).
+  const bool fused3 = !c.bf && c.prec == 3 && g_bf16_variant != 56 && xattn3_supported(dh, N) && l.sd_q.lo && D % 32 == 0 &&
+                      (c.M * D) % 8 == 0;
+  if (fused3) {
+    uint16_t* const qh = (uint16_t*)w.t1;
+    uint16_t* const ql = qh + c.M * D;
+    GemmArgs g = gd(c);
+    g.A = op_f32(x, D);
+    g.W = packed(l.sd_q);
+    g.M = (int)c.M, g.N = D, g.K = D;
+    g.bias = l.sd_q_b, g.alpha = 1.f / sqrtf((float)dh);
+    g.C16 = qh, g.C16_lo = ql, g.ldc = D;
+    MDM_TRY(gemm(g, c.s));
+    MDM_TRY(sd_attn3(qh, ql, kc, vc, c.ntok, c.B, c.S, H, dh, N, w.t2, c.s));
+  } else {
     LinOpts o;
     o.alpha = 1.f / sqrtf((float)dh);
     const bool fz = c.bf && xattn_supported(dh, N) && !(dh == 256 && g_bf16_variant == 23);
     MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.sd_q, l.sd_q_b, D, fz ? nullptr : w.t1,
                    fz ? (uint16_t*)w.t1 : nullptr, o));
   }
-  if (c.bf && xattn_supported(dh, N) && !(dh == 256 && g_bf16_variant == 23)) {
+  if (fused3) {
+  } else if (c.bf && xattn_supported(dh, N) && !(dh == 256 && g_bf16_variant == 23)) {
     MDM_TRY(sd_attn(w.t1, c.h16, kc, vc, c.B, c.S, H, dh, N, (uint16_t*)w.t2, nullptr, c.h16, c.s, c.ntok));  // scores, softmax, PV fused
   } else {
     {

@@ -77,7 +77,12 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bfr& hi, 
   hi = __builtin_bit_cast(bfr, h);
   lo = __builtin_bit_cast(bfr, l);
 }
-__device__ __forceinline__ float feat(float z) { return 0.1f * expf(fminf(fmaxf(z, -15.f), 15.f)); }  // (:58-66)
+// feature map 0.1 exp(clamp(z, +-15)) (:58-66) on the hardware exp2: z = q^ . P column with |q^| = 1 and |P column| = dh^-1/4, so
+// |z| <= 0.3 and v_exp_f32's error (~1 ulp of the result, plus the rounding of z log2 e: < 2e-8 relative here) is at the level of
+// libm's; the clamp is kept for inputs that are not normalised.  libm's expf costs ~25 instructions, 64 of them per frame tile.
+__device__ __forceinline__ float feat(float z) {
+  return 0.1f * __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(z, -15.f, 15.f) * 1.44269504088896340736f);
+}
 
 struct Attn3Args {
   const uint16_t* xh;  // q^ | k^ | v^ hi plane [B S, 3 D]
@@ -200,6 +205,21 @@ __global__ __launch_bounds__(A3_NT) void perf_attn3_kernel(const Attn3Args g) {
       kv[j] = mm3(vh, vl, xh, xl, kv[j]);  // D[d][m]: m = r16, d = 16 j + 4 q + reg
     }
   }
+  // pass 2's operands of this wave's first frame tile are requested now: they land under the state's write and its barriers
+  const int ntile = (S + 15) >> 4;
+  bfr qh[4], ql[4], kh[4], kl[4];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int t = tile * 16 + r16;
+    const int64_t ro = (rowbase + (t < S ? t : S - 1)) * D3 + h * A3_DH + 8 * q;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qh[ks] = *(const bfr*)(g.xh + ro + 32 * ks);
+      ql[ks] = *(const bfr*)(g.xl + ro + 32 * ks);
+      kh[ks] = *(const bfr*)(g.xh + ro + D + 32 * ks);
+      kl[ks] = *(const bfr*)(g.xl + ro + D + 32 * ks);
+    }
+  };
+  fetch(wid < ntile ? wid : ntile - 1);
   a3_barrier();  // every wave is done reading the ring: its LDS takes the state
   // KV^T x 0.1 (:77) as hi / lo planes [d][128]; column m sits at position 32 (m >> 5) + 8 ((m & 15) >> 2) + 4 ((m >> 4) & 1) + (m & 3):
   // the 8 k slots a lane of pass 2 multiplies are then one 16-byte read
@@ -221,7 +241,6 @@ __global__ __launch_bounds__(A3_NT) void perf_attn3_kernel(const Attn3Args g) {
   a3_barrier();
 
   // ---- pass 2: per frame tile  qphi, kphi -> den;  num = qphi KV;  LN(0.1 num / den) -> out ---------------------------------
-  const int ntile = (S + 15) >> 4;
 #pragma unroll 1
   for (int tile = wid; tile < ntile; tile += 8) {
     const int t0 = tile * 16, t = t0 + r16;
@@ -229,15 +248,6 @@ __global__ __launch_bounds__(A3_NT) void perf_attn3_kernel(const Attn3Args g) {
     // fragment reads (512 registers) out of this loop and parks them in scratch memory
     int ro16 = r16 * 256, rx = r16;
     asm volatile("" : "+v"(ro16), "+v"(rx));
-    const int64_t ro = (rowbase + (t < S ? t : S - 1)) * D3 + h * A3_DH + 8 * q;
-    bfr qh[4], ql[4], kh[4], kl[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qh[ks] = *(const bfr*)(g.xh + ro + 32 * ks);
-      ql[ks] = *(const bfr*)(g.xl + ro + 32 * ks);
-      kh[ks] = *(const bfr*)(g.xh + ro + D + 32 * ks);
-      kl[ks] = *(const bfr*)(g.xl + ro + D + 32 * ks);
-    }
     f32x4 aq[8], ak[8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) aq[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}, ak[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -250,6 +260,7 @@ __global__ __launch_bounds__(A3_NT) void perf_attn3_kernel(const Attn3Args g) {
         aq[mt] = mm3(ah, al, qh[ks], ql[ks], aq[mt]);  // D[m][t]: t = r16, m = 16 mt + 4 q + reg
         ak[mt] = mm3(ah, al, kh[ks], kl[ks], ak[mt]);
       }
+    if (tile + 8 < ntile) fetch(tile + 8);  // the fragments are consumed: the next tile's land under the rest of this one
     const bool valid = t < nvalid;
     float den = 0.f;
 #pragma unroll

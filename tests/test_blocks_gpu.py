@@ -147,13 +147,13 @@ def test_sd_fold_matches_unfolded_chain(S, N, B):
     assert not torch.equal(folded, chain)  # the knob really selects two different code paths
 
 
-@pytest.mark.parametrize("precision,knob", [(3, 0), (2, 0), (2, 22), (1, 24), (2, 24)])
+@pytest.mark.parametrize("precision,knob", [(3, 0), (3, 56), (4, 0), (2, 0), (2, 22), (1, 24), (2, 24)])
 @pytest.mark.parametrize("S,N,counts", [(98, 28, [28, 9, 17]), (40, 64, [1, 64, 33]), (196, 85, [85, 10, 47])])
 def test_per_sample_token_counts_equal_each_sample_run_with_its_own_tokens(S, N, counts, precision, knob):
     """MdmTextCache.ntok: samples whose captions have different token counts travel in one batch, padded to N rows; both
     text cross-attentions must give every sample what it gets when run alone with exactly its own tokens (what the reference
     computes: it has no text mask, so it can only run such samples in separate forwards), whatever the padding rows hold.
-    Paths: fp32-grade chain (row softmax), folded kernel (knob 24 forces it), attention-core kernel (knob 22), and against
+    Paths: fp32-grade one-launch cores (csrc/xattn3.hip) and their chain (knob 56: row softmax), folded kernel (knob 24 forces it), attention-core kernel (knob 22), and against
     the oracle on the sample's own tokens."""
     B = len(counts)
     m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, precision)
@@ -164,7 +164,7 @@ def test_per_sample_token_counts_equal_each_sample_run_with_its_own_tokens(S, N,
     xf_pad = xf.clone()
     for b, n in enumerate(counts):
         xf_pad[b, n:] = pad[b, n:]
-    tol = {3: 2e-5, 2: 2e-3, 1: 1.5e-2}[precision]
+    tol = {3: 2e-5, 4: 2e-5, 2: 2e-3, 1: 1.5e-2}[precision]
     L.lib().mdm_set_gemm_variant(knob)
     try:
         for block, ref_fn in ((L.BLOCK_CROSS, "cross"), (L.BLOCK_SDCROSS, "sd")):
@@ -334,3 +334,27 @@ def test_fp32_grade_attention_core_in_one_launch(B, S, precision):
     print(f"B={B} S={S} precision={precision}: fused vs oracle {e_ref:.2e}, chain vs oracle {rel_inf(chain, ref):.2e}, fused vs chain {e_chain:.2e}")
     assert torch.isfinite(out).all()
     assert e_ref < 1e-3 and e_chain < 2e-4
+
+
+@pytest.mark.parametrize("precision", [3, 4])
+@pytest.mark.parametrize("B,S,N", [(2, 98, 28), (3, 196, 85), (2, 40, 6), (1, 6, 128), (2, 196, 33), (2, 50, 64)])
+def test_fp32_grade_text_cross_attention_cores_in_one_launch(B, S, N, precision):
+    """csrc/xattn3.hip behind the plane / head-softmax epilogues of the query projections (csrc/gemm3.hip): the linear and the
+    softmax text cross-attention of the fp32-grade modes against (a) the chains they replace (knob 56) and (b) the oracle;
+    1, 2, 3 and 4 key steps of 32 tokens, frame counts that are not multiples of 16."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, precision)
+    L = pkg("_lib")
+    with torch.no_grad():
+        refs = {L.BLOCK_CROSS: R.gated_cross_attention(h, xf, emb, sd, pre + ".cross_attn", H, eph["low.0.cross_style"]),
+                L.BLOCK_SDCROSS: R.softmax_cross_ffn(h, xf, sd, pre + ".sd_cross_attn", H)}
+    for block, ref in refs.items():
+        out = _run_block(m, block, h, sc, length, xf)
+        L.lib().mdm_set_gemm_variant(56)
+        try:
+            chain = _run_block(m, block, h, sc, length, xf)
+        finally:
+            L.lib().mdm_set_gemm_variant(0)
+        e_ref, e_chain = rel_inf(out, ref), rel_inf(out, chain)
+        print(f"block {block} B={B} S={S} N={N} precision={precision}: fused vs oracle {e_ref:.2e}, chain vs oracle {rel_inf(chain, ref):.2e}, fused vs chain {e_chain:.2e}")
+        assert torch.isfinite(out).all()
+        assert e_ref < 1e-3 and e_chain < 2e-4  # (the two paths may agree bit for bit: same split products, same k order)
