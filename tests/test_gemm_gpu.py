@@ -229,7 +229,8 @@ def force_256():
     L.lib().mdm_set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(512, 256, 64, 0), (12544, 512, 512, 1), (700, 768, 128, 2), (255, 1024, 192, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(512, 256, 64, 0), (12544, 512, 512, 1), (700, 768, 128, 2), (255, 1024, 192, 0), (6272, 1024, 1024, 0),
+                                        (1000, 256, 4096, 1)])
 def test_bf16_256_tile_kernel(force_256, M, N, K, act):
     L, ops = _mods()
     x, w, b = _rand(M, K, seed=41), _rand(N, K, seed=42), _rand(N, seed=43)
