@@ -85,7 +85,7 @@ def usable_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=32, nsteps=3):
+def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=16, nsteps=2):
     """The oracle (CPU restatement, pinned to the reference by golden vectors) timed on this host: one CFG step
     (2 forwards) on a bounded sample of the batch, scaled linearly to the full batch (samples are independent)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -126,6 +126,33 @@ def cpu_baseline(host, inputs, steps_total, cfg_scale, sample_rows=32, nsteps=3)
     return {"value": 1.0 / full, "unit": "denoising-steps/sec", "cores": cores, "kind": "port", "cpu_model": cpu_model,
             "sample": f"{nsteps} CFG steps (2 forwards each) of the torch-CPU oracle (fp32) on {n} of the {B} samples, "
                       f"T={x.shape[1]}, {dt:.1f} s per step measured" + (f", scaled x{B / n:g} to the batch" if n != B else "")}
+
+
+def source_sha16() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): ties a committed counter profile to the code it was
+    measured on (tools/pmc_traffic.py stores the same hash)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pk = os.path.join(ROOT, "motiondiffusion-moe_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(pk, "*.hip")) + glob.glob(os.path.join(pk, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(precision: int):
+    """Fabric bytes from the committed rocprofv3 --pmc passes (profiles/r04_pmc_traffic_p<precision>.json), or (None, why).  The
+    profile is used only if it was taken on exactly these kernel sources; a stale one is reported as stale, not printed."""
+    f = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_p{precision}.json")
+    if not os.path.exists(f):
+        return None, f"no counter profile committed for precision {precision}"
+    j = json.load(open(f))
+    if j.get("src_sha16") != source_sha16():
+        return None, (f"profiles/{os.path.basename(f)} was measured at commit {j.get('commit', '?')} on kernel sources "
+                      f"{j.get('src_sha16')}, the sources are now {source_sha16()}: stale, not reported")
+    return j, (f"fabric bytes from rocprofv3 --pmc FETCH_SIZE(x2) / WRITE_SIZE passes, profiles/{os.path.basename(f)}, measured at commit "
+               f"{j.get('commit', '?')} on these kernel sources ({j.get('src_sha16')})")
 
 
 def time_block(fn, iters=20):
@@ -224,7 +251,7 @@ def probe_dominant_kernel(r, m, steps=3):
     return t, flop, pairs
 
 
-def mode_table(a, m_main, inputs, host, diff, kw, dev, main_prec, main_ms, steps=10, warmup=3):
+def mode_table(a, m_main, inputs, host, diff, kw, dev, main_prec, main_ms, steps=6, warmup=2):
     """Every precision mode on the SAME workload: ms per guided step (graph replay) and, for one forward of the cond half,
     the error and the routing decisions that differ relative to the parity-grade mode (bf16x3; its own error against the
     CPU oracle is gated in tests/test_round2_gpu.py).  No oracle is involved here: HIP against HIP on identical inputs."""
@@ -271,8 +298,27 @@ def mode_table(a, m_main, inputs, host, diff, kw, dev, main_prec, main_ms, steps
                 step()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / steps * 1e3
+            live3 = None
+            if prec == 3:  # the parity mode's own roofline entry: its dominant kernels, timed live inside real (eager) steps
+                r.t_dev.fill_(a.schedule - 1)
+                live3 = probe_dominant_kernel(r, m, steps=2)
             del r
         res[prec] = {"precision": prec, "dtype": DTYPE[prec], "ms_per_step": round(ms, 3), "steps_per_s": round(1e3 / ms, 2)}
+        if prec == 3 and prec != main_prec:
+            flop_step = 2.0 * CONFIGS[a.config][1] * (B / 32.0) * (T / 196.0)
+            res[3]["roofline"] = {
+                "bound": "mfma", "peak": round(PEAK[3] / 1e12, 1), "unit": "TFLOP/s",
+                "peak_note": "2.5 PF dense bf16 / 3: every fp32-grade product is three bf16 MFMAs (hi*lo + lo*hi + hi*hi)",
+                "whole_step": {"achieved": round(flop_step / (ms * 1e-3) / 1e12, 2), "frac": round(flop_step / (ms * 1e-3) / PEAK[3], 4)}}
+            if live3 is not None:
+                res[3]["roofline"].update({
+                    "achieved": round(live3[1] / live3[0] / 1e12, 2), "frac": round(live3[1] / live3[0] / PEAK[3], 4),
+                    "kernel": "gemm_x3_kernel<128, 128, 2, GELU | none> x 2: the expert MLP as its two grouped bf16x3 GEMMs (csrc/gemm3.hip), "
+                              "the dominant kernels of this mode",
+                    "what": "mean algorithmic FLOP per expert-MLP launch pair (4 * routed rows * D * F) / mean duration of the pair, HIP "
+                            "events on the launch stream inside real sampling steps (mdm_probe_*)",
+                    "launch_us_mean": round(live3[0] * 1e6, 1), "launches_timed": len(live3[2]),
+                    "launches": [{"rows": rw, "us": round(u, 1)} for rw, u in live3[2][:8]]})
         if prec != main_prec:
             del m
             torch.cuda.empty_cache()
@@ -353,7 +399,7 @@ def dry_run(a, world, rank) -> None:
         dist.destroy_process_group()
 
 
-def other_config_line(cfg_name, sampler, schedule, a, dev, steps=12, warmup=3, batch=None, precision=None):
+def other_config_line(cfg_name, sampler, schedule, a, dev, steps=8, warmup=2, batch=None, precision=None):
     """One more BASELINE config timed in the same process (graph-replayed steps on the same device; the headline's precision and
     per-GPU batch unless given): the driver's record then carries the big model too.  Returns the numbers, not a full bench line."""
     D_ = importlib.import_module("motiondiffusion-moe_amd.diffusion")
@@ -401,9 +447,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="small", choices=list(CONFIGS))
-    ap.add_argument("--precision", type=int, default=2, choices=[1, 2, 3, 4, 5],
-                    help="1 = bf16 MFMA, 2 = fp16 MFMA (default: same speed, 8x smaller error), 3 = bf16x3 fp32-grade, "
-                         "4 = mixed (bf16x3 + fp16 expert/FFN GEMMs)")
+    ap.add_argument("--precision", type=int, default=1, choices=[1, 2, 3, 4, 5],
+                    help="1 = bf16 MFMA (default: the format BASELINE configs[1] names), 2 = fp16 MFMA (same speed, 8x smaller error), "
+                         "3 = bf16x3 fp32-grade (the only mode inside the 1e-3 parity bound: always reported beside the headline as "
+                         "parity_mode), 4 = mixed (bf16x3 + fp16 expert/FFN GEMMs)")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-mode timing / error table")
     ap.add_argument("--sampler", default="cfg", choices=["cfg", "ddim"],
                     help="cfg = guided DDPM step (2 forwards batched; configs[1], [2]); ddim = DDIM step (1 forward; configs[3])")
@@ -516,10 +563,11 @@ def main():
         live = probe_dominant_kernel(r, m) if not r.chunks else None  # single-stream steps only
         # (the per-mode table is a single-GPU report: a scaling run keeps rank 0 no longer than the other ranks)
         modes = None if (a.no_modes or world > 1 or a.sampler != "cfg" or a.config != "small") else mode_table(a, m, inputs, host, diff, kw, dev, a.precision, ms)
-        traffic = None  # HBM-side bytes per step from the committed PMC passes (same workload only)
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        if os.path.exists(pmc) and (a.config, B, T, a.precision, a.sampler) == ("small", 32, 196, 2, "cfg"):
-            traffic = json.load(open(pmc))["total_bytes_per_step"]
+        # fabric bytes per step from the committed rocprofv3 --pmc passes -- only for this exact workload AND these kernel sources
+        pmc_j, traffic_note = (None, "the committed counter profiles are of the default workload (small, B=32, T=196, CFG)")
+        if (a.config, B, T, a.sampler) == ("small", 32, 196, "cfg"):
+            pmc_j, traffic_note = committed_traffic(a.precision)
+        traffic = pmc_j["total_bytes_per_step"] if pmc_j else None
         cfgname = {"small": "configs[1]", "big": "configs[2]" if a.sampler == "cfg" else "configs[3]", "big16": "configs[4]"}[a.config]
         stepdesc = (f"{a.schedule}-step DDPM with CFG {a.cfg_scale} (cond+uncond batched as {2 * B} rows)" if a.sampler == "cfg"
                     else f"{a.schedule}-step DDIM (eta 0, one forward per step)")
@@ -538,8 +586,7 @@ def main():
             "ms_per_forward": round(ms / nfwd, 3),
             "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": PEAK[a.precision] / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK[a.precision], 4), "traffic": traffic,
-                         "traffic_note": "fabric bytes per step from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, "
-                                         "profiles/r03_pmc_traffic.json" if traffic else None,
+                         "traffic_note": traffic_note,
                          "what": "whole step: algorithmic FLOP of 2 forwards / wall time per step",
                          "whole_step": {"achieved": round(achieved / 1e12, 2), "frac": round(achieved / PEAK[a.precision], 4),
                                         "traffic": traffic},
@@ -556,16 +603,15 @@ def main():
         if live is not None:
             # the contract's roofline entry: the dominant kernel (26 % of the step, profiles/r01_kernel_stats.txt), live
             pmc_k = None
-            if traffic is not None:
-                per = json.load(open(pmc))["per_kernel_MB_per_call"]
+            if pmc_j is not None:
+                per = pmc_j["per_kernel_MB_per_call"]
                 per = per.items() if isinstance(per, dict) else per
-                pk = next((v for k, v in per if str(k).startswith("fused_mlp")), None)
+                pk = next((v for k, v in per if str(k).startswith("fused_mlp_stream_kernel") and ", 7, 4, 512, 0>" in str(k)), None)
                 pmc_k = (pk["fetch_x2"] + pk["write"]) * 1e6 if pk else None
             rf = line["roofline"]
             rf.update({"achieved": round(live[1] / live[0] / 1e12, 2), "frac": round(live[1] / live[0] / PEAK[a.precision], 4),
                        "traffic": pmc_k,
-                       "traffic_note": "fabric bytes per launch of this kernel (mean over its launches in a step), rocprofv3 "
-                                       "--pmc FETCH_SIZE(x2) / WRITE_SIZE passes, profiles/r03_pmc_traffic.json" if pmc_k else None,
+                       "traffic_note": ("per launch of this kernel (mean over its launches in a step); " + traffic_note) if pmc_k else traffic_note,
                        "what": "dominant kernel fused_mlp_stream_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip): mean algorithmic FLOP per "
                                "launch (4 * routed rows * D * F) / mean launch duration over the launches of real sampling "
                                "steps; the whole step is under whole_step",

@@ -157,6 +157,10 @@ int mdm_mlp_stream_pack(const float* w1, const float* w2, int32_t G, int32_t F, 
  * the buffer needs (0 = shape not taken) and the packer. */
 int64_t mdm_gemm_stream_elems(int32_t N, int32_t K);
 int mdm_gemm_stream_pack(const float* w, int32_t N, int32_t K, int32_t h16, uint16_t* out, void* stream);
+/* the same for the fp32-grade (bf16x3) form of that kernel: (bf16 hi, lo = rn(w - hi)) fragment PAIRS in consumption order,
+ * 2 * N * K + 16 KiB of tail padding elements (0 = shape not taken) */
+int64_t mdm_gemm_stream3_elems(int32_t N, int32_t K);
+int mdm_gemm_stream3_pack(const float* w, int32_t N, int32_t K, uint16_t* out, void* stream);
 
 /* fp32 [rows, K] (row stride ld_src) -> bf16 planes [rows, Kpad] (Kpad = ld_dst, multiple of 32, zero padded);
  * lo may be NULL.  Weight packing happens once at load time (not on the hot path). */
@@ -180,6 +184,7 @@ typedef struct MdmStyle { /* StylizationBlock minus its emb_layers (those are st
   MdmPacked out; /* out_layers.2 [D,D] */
   const float* out_b;
   const uint16_t* out_ws; /* optional weight stream of out_layers.2 (mdm_gemm_stream_pack; 16-bit modes, D == 512), or NULL */
+  const uint16_t* out_ws3; /* optional (hi, lo) pair stream of out_layers.2 (mdm_gemm_stream3_pack; fp32-grade modes, D == 512), or NULL */
 } MdmStyle;
 
 typedef struct MdmPerformer { /* PerformerSelfAttention, fast_attention.py:94-179 */

@@ -66,7 +66,8 @@ class Packed(C.Structure):
 
 
 class Style(C.Structure):
-    _fields_ = [("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("out", Packed), ("out_b", C.c_void_p), ("out_ws", C.c_void_p)]
+    _fields_ = [("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("out", Packed), ("out_b", C.c_void_p), ("out_ws", C.c_void_p),
+                ("out_ws3", C.c_void_p)]
 
 
 class Performer(C.Structure):
@@ -132,7 +133,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mdm_version.restype = C.c_char_p
         for name in EXPORTS:
-            if name in ("mdm_workspace_bytes", "mdm_text_head_workspace_bytes", "mdm_moe_train_workspace_bytes", "mdm_mlp_stream_elems", "mdm_gemm_stream_elems"):
+            if name in ("mdm_workspace_bytes", "mdm_text_head_workspace_bytes", "mdm_moe_train_workspace_bytes", "mdm_mlp_stream_elems", "mdm_gemm_stream_elems", "mdm_gemm_stream3_elems"):
                 getattr(L, name).restype = C.c_int64
             elif name != "mdm_version":
                 getattr(L, name).restype = C.c_int
@@ -141,7 +142,7 @@ def lib():
 
 
 # every symbol include/mdm_hip.h declares (checked by tests/test_abi.py)
-EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_mlp_stream_elems", "mdm_mlp_stream_pack", "mdm_gemm_stream_elems", "mdm_gemm_stream_pack", "mdm_pack_bf16", "mdm_pack_f16", "mdm_pack_fp8", "mdm_workspace_bytes", "mdm_text_cache_build",
+EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_mlp_stream_elems", "mdm_mlp_stream_pack", "mdm_gemm_stream_elems", "mdm_gemm_stream_pack", "mdm_gemm_stream3_elems", "mdm_gemm_stream3_pack", "mdm_pack_bf16", "mdm_pack_f16", "mdm_pack_fp8", "mdm_workspace_bytes", "mdm_text_cache_build",
            "mdm_denoiser_forward", "mdm_stem_cache_build", "mdm_block_forward", "mdm_moe_ffn_forward", "mdm_dual_self_attn_forward", "mdm_linear_xattn_forward",
            "mdm_softmax_xattn_ffn_forward", "mdm_performer_attn_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
            "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_noise_normal", "mdm_noise_normal_ids", "mdm_text_head_workspace_bytes", "mdm_text_head_forward", "mdm_motion_postprocess", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant", "mdm_diag_build", "mdm_diag_mlp_counters", "mdm_debug_stamps", "mdm_probe_enable", "mdm_probe_read", "mdm_route_dump",

@@ -100,6 +100,12 @@ int mdm_gemm_stream_pack(const float* w, int32_t N, int32_t K, int32_t h16, uint
   return mdm::gemm_stream_pack(w, N, K, h16, out, (hipStream_t)stream);
 }
 
+int64_t mdm_gemm_stream3_elems(int32_t N, int32_t K) { return mdm::gemm_stream3_elems(N, K); }
+
+int mdm_gemm_stream3_pack(const float* w, int32_t N, int32_t K, uint16_t* out, void* stream) {
+  return mdm::gemm_stream3_pack(w, N, K, out, (hipStream_t)stream);
+}
+
 int mdm_pack_bf16(const float* src, int64_t ld_src, int64_t rows, int64_t K, uint16_t* hi, uint16_t* lo,
                   int64_t ld_dst, void* stream) {
   if (!src || !hi || rows < 0 || K <= 0 || ld_dst < K || (ld_dst & 31)) return MDM_ERR_ARG;

@@ -91,6 +91,12 @@ int mlp_stream_pack(const float* w1, const float* w2, int G, int F, int Din, int
 int64_t gemm_stream_elems(int N, int K);
 int gemm_stream_pack(const float* w, int N, int K, int h16, uint16_t* out, hipStream_t stream);
 bool style_gemm_supported(int D, int64_t M);
+// fp32-grade form: fp32 source rows, bf16x3 products, (hi, lo) fragment pair stream
+int64_t gemm_stream3_elems(int N, int K);
+int gemm_stream3_pack(const float* w, int N, int K, uint16_t* out, hipStream_t stream);
+int style_gemm3(const float* src, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
+                const float* sc, const int* pos4, const uint16_t* ws3, const float* bias, const float* resid, float out_scale,
+                const float* colscale, float* out, hipStream_t s);
 int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
                const float* sc, const int* pos4, const uint16_t* ws, const float* bias, const float* resid, float out_scale,
                const float* colscale, float* out, uint16_t* out16, int h16, hipStream_t s);

@@ -189,6 +189,9 @@ int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float*
   if (c.bf && st.out_ws && g_bf16_variant != 30 && style_gemm_supported(D, c.M))  // one launch (csrc/style_gemm.hip); knob 30: two
     return style_gemm(src, src_bf16 ? c.h16 : 0, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, st.out_ws, st.out_b, resid,
                       out_scale, colscale, out, out16, c.h16, c.s);
+  // fp32-grade modes: the same fusion on bf16x3 products (csrc/style_gemm.hip style_gemm3; knob 60: two launches)
+  if (!c.bf && c.prec == 3 && !src_bf16 && !out16 && st.out_ws3 && g_bf16_variant != 60 && style_gemm_supported(D, c.M))
+    return style_gemm3(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, st.out_ws3, st.out_b, resid, out_scale, colscale, out, c.s);
   MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, src_bf16 ? c.h16 : 0, tmp, fmt16(c), c.s));
   LinOpts o;
   o.out_scale = out_scale, o.R1 = resid, o.colscale = colscale;
@@ -519,6 +522,9 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     }
     return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, y16);
   }
+  // measurement probe of the fp32-grade modes: the expert MLP as its two grouped GEMMs, bracketed like the fused kernel above
+  const bool pr2 = g_probe.on && g_probe.n < PROBE_MAX;
+  if (pr2 && hipEventRecord(g_probe.a[g_probe.n], c.s) != hipSuccess) return MDM_ERR_LAUNCH;
   {
     GemmArgs g = gd(c);  // hidden = GELU(LN_b(x)[routed rows] W1_e^T + b1_e)
     if (h) {
@@ -551,6 +557,10 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     g.rowscale = w.rowscale;
     g.C = w.y2, g.ldc = D;  // fp32: the four routed rows of a token are summed in the stylization kernel
     MDM_TRY(gemm(g, c.s));
+  }
+  if (pr2) {
+    if (hipEventRecord(g_probe.b[g_probe.n], c.s) != hipSuccess) return MDM_ERR_LAUNCH;
+    g_probe.rows[g_probe.n++] = f.M;
   }
   // mean of the two branches (each the sum of its two routed rows), stylization, residual
   return style_apply(c, l.ffn_style, w.y2, nullptr, nullptr, w.pos4, sc, w.t2, x, 1.f, nullptr, out, out16, false);

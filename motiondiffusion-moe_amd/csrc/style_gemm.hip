@@ -195,6 +195,174 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
   }
 }
 
+// ---- the same launch in the fp32-grade (bf16x3) arithmetic ---------------------------------------------------------------------
+// Row phase in fp32 exactly as above (the source rows are fp32 in these modes); the rows are left as TWO 16-bit images (bf16 hi and
+// lo = rn(x - hi)) and every product is three MFMAs (Wh Al + Wl Ah + Wh Ah, small terms first as csrc/gemm3.hip).  Wout streams as
+// (hi, lo) fragment PAIRS (mdm_gemm_stream3_pack: per wave the 64 pairs of its 64 columns in K order, 2 KiB per pair).  A weight
+// fragment pair feeds 3 RT MFMAs instead of RT: at the same stream rate three times the matrix work of the 16-bit launch, which is
+// what this mode's arithmetic costs anyway -- the launch replaces style_in + a 128 x 128-tile bf16x3 GEMM (whose fp32 operand
+// tiles cross L2 -> LDS four times) and the fp32 [M, D] tensor between them.
+template <int SG_RT>
+__global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm3_kernel(const StyleGemmArgs g) {
+  constexpr int SG_ROWS = 16 * SG_RT, RPW = SG_ROWS / 8;
+  typedef HB::frag_t frag_t;
+  typedef Row<8, true> R8;
+  constexpr int D = SG_D, IMG = SG_ROWS * 1024;
+  extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
+  uint8_t* const imh = smem;
+  uint8_t* const iml = smem + IMG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * SG_ROWS;
+
+  // the wave's stream: 64 (hi, lo) pairs = 128 fragments of 1 KiB; fragment f of the stream refills ring slot f % NR
+  const uint8_t* wp = (const uint8_t*)g.ws + (int64_t)wn * 128 * 1024 + lane * 16;
+  constexpr int NR = SG_RT <= 2 ? 8 : 16;
+  frag_t R[NR];
+#pragma unroll
+  for (int f = 0; f < (NR < 8 ? NR : 8); ++f) R[f] = *(const frag_t*)(wp + f * 1024);
+
+  {
+    R8 pww, pbb, sww, sbb;
+    if (g.pw) pww.load(g.pw, D, lane), pbb.load(g.pb, D, lane);
+    sww.load(g.sw, D, lane), sbb.load(g.sb, D, lane);
+#pragma unroll 2
+    for (int q = 0; q < RPW; ++q) {
+      const int rl = RPW * wn + q;
+      int64_t row = row0 + rl;
+      row = row < g.M ? row : g.M - 1;
+      const float* scb = g.sc + (row / g.S) * 2 * (int64_t)D;
+      R8 r, scale, shift;
+      scale.load(scb, D, lane);
+      shift.load(scb + D, D, lane);
+      const float* x = (const float*)g.src;
+      if (g.pos4) {
+        const int p0 = g.pos4[row * 4 + 0], p1 = g.pos4[row * 4 + 1], p2 = g.pos4[row * 4 + 2], p3 = g.pos4[row * 4 + 3];
+        R8 a, b, c, d;
+        a.load(x + (int64_t)p0 * D, D, lane);
+        b.load(x + (int64_t)p1 * D, D, lane);
+        c.load(x + (int64_t)p2 * D, D, lane);
+        d.load(x + (int64_t)p3 * D, D, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.e[j] = ((a.e[j] + b.e[j]) + (c.e[j] + d.e[j])) * 0.5f;
+      } else {
+        r.load(x + row * D, D, lane);
+      }
+      if (g.pw) {
+        r.layernorm(pww, pbb, D, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += r.e[j] * r.e[j];
+        const float inv = sqrtf((float)D) / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.e[j] *= inv;
+      }
+      r.layernorm(sww, sbb, D, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.e[j] = silu(r.e[j] * (1.f + scale.e[j]) + shift.e[j]);
+      uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+      split_bf16(r.e[0], r.e[1], h0, l0);
+      split_bf16(r.e[2], r.e[3], h1, l1);
+      split_bf16(r.e[4], r.e[5], h2, l2);
+      split_bf16(r.e[6], r.e[7], h3, l3);
+      const int o0 = rl * 1024 + ((((lane >> 1)) ^ (rl & 15)) << 4) + (lane & 1) * 8;
+      const int o1 = rl * 1024 + (((32 + (lane >> 1)) ^ (rl & 15)) << 4) + (lane & 1) * 8;
+      *(uint2*)(imh + o0) = make_uint2(h0, h1), *(uint2*)(imh + o1) = make_uint2(h2, h3);
+      *(uint2*)(iml + o0) = make_uint2(l0, l1), *(uint2*)(iml + o1) = make_uint2(l2, l3);
+    }
+  }
+#pragma unroll
+  for (int f = 8; f < NR; ++f) R[f] = *(const frag_t*)(wp + f * 1024);
+  wp += NR * 1024;
+  sg_barrier();
+
+  const int frow = lane & 15, fq = lane >> 4;
+  f32x4 y[SG_RT][SG_NJ];
+#pragma unroll
+  for (int i = 0; i < SG_RT; ++i)
+#pragma unroll
+    for (int j = 0; j < SG_NJ; ++j) y[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const int xb = frow * 1024 + ((fq ^ frow) << 4);
+    frag_t Ah[2][SG_RT], Al[2][SG_RT];
+#pragma unroll
+    for (int i = 0; i < SG_RT; ++i) Ah[0][i] = *(const frag_t*)(imh + xb + i * 16384), Al[0][i] = *(const frag_t*)(iml + xb + i * 16384);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) {
+#pragma unroll
+        for (int i = 0; i < SG_RT; ++i) {
+          const int off = (xb ^ (64 * ((s + 1) & 3))) + ((s + 1) >> 2) * 256 + i * 16384;
+          Ah[(s + 1) & 1][i] = *(const frag_t*)(imh + off), Al[(s + 1) & 1][i] = *(const frag_t*)(iml + off);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SG_NJ; ++j) {
+        const int slot = (2 * (s * SG_NJ + j)) & (NR - 1);
+#pragma unroll
+        for (int i = 0; i < SG_RT; ++i) {
+          y[i][j] = HB::mfma16(R[slot], Al[s & 1][i], y[i][j]);
+          y[i][j] = HB::mfma16(R[slot + 1], Ah[s & 1][i], y[i][j]);
+          y[i][j] = HB::mfma16(R[slot], Ah[s & 1][i], y[i][j]);
+        }
+        R[slot] = *(const frag_t*)(wp + slot * 1024);  // the last NR refills read (and discard) the next wave's / the padding
+        R[slot + 1] = *(const frag_t*)(wp + (slot + 1) * 1024);
+        if (slot + 2 == NR) wp += NR * 1024;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  sg_barrier();
+  float* stg = (float*)smem;
+#pragma unroll
+  for (int j = 0; j < SG_NJ; ++j) {
+    const int n = wn * 64 + 16 * j + 4 * fq;
+    f32x4 bb = *(const f32x4*)(g.bias + n);
+    f32x4 cs = {g.out_scale, g.out_scale, g.out_scale, g.out_scale};
+    if (g.colscale) {
+      const f32x4 q = *(const f32x4*)(g.colscale + n);
+      cs[0] *= q[0], cs[1] *= q[1], cs[2] *= q[2], cs[3] *= q[3];
+    }
+#pragma unroll
+    for (int i = 0; i < SG_RT; ++i) {
+      const int ml = i * 16 + frow;
+      f32x4 v = y[i][j];
+      v[0] = (v[0] + bb[0]) * cs[0], v[1] = (v[1] + bb[1]) * cs[1], v[2] = (v[2] + bb[2]) * cs[2], v[3] = (v[3] + bb[3]) * cs[3];
+      *(f32x4*)(stg + ml * D + (((n >> 2) ^ (ml & 31)) << 2)) = v;
+    }
+  }
+  sg_barrier();
+  const int cl = tid & 127, n = 4 * cl;
+#pragma unroll
+  for (int k = 0; k < SG_ROWS / 4; ++k) {
+    const int ml = (tid >> 7) + 4 * k;
+    const int64_t m = row0 + ml;
+    if (m >= g.M) continue;
+    f32x4 v = *(const f32x4*)(stg + ml * D + ((cl ^ (ml & 31)) << 2));
+    if (g.resid) {
+      const f32x4 q = *(const f32x4*)(g.resid + m * D + n);
+      v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
+    }
+    *(f32x4*)(g.out + m * D + n) = v;
+  }
+}
+
+// stream3[wave w][pair p = 4 s + j][plane hi | lo][lane l][8]:  bf16 hi / lo of W[64 w + 16 j + (l & 15)][32 s + 8 (l >> 4) + e]
+__global__ __launch_bounds__(256) void gemm_stream3_pack_kernel(const float* w, uint16_t* out) {
+  for (int fi = blockIdx.x * 4 + (threadIdx.x >> 6); fi < 8 * 64; fi += gridDim.x * 4) {
+    const int l = threadIdx.x & 63, wv = fi >> 6, f = fi & 63, s = f >> 2, j = f & 3;
+    const float* src = w + (int64_t)(64 * wv + 16 * j + (l & 15)) * SG_D + 32 * s + 8 * (l >> 4);
+    uint4 h, lo;
+    split_bf16(src[0], src[1], h.x, lo.x);
+    split_bf16(src[2], src[3], h.y, lo.y);
+    split_bf16(src[4], src[5], h.z, lo.z);
+    split_bf16(src[6], src[7], h.w, lo.w);
+    *(uint4*)(out + (int64_t)fi * 1024 + l * 8) = h;
+    *(uint4*)(out + (int64_t)fi * 1024 + 512 + l * 8) = lo;
+  }
+}
+
 // stream[wave w][fragment f = 4 s + j][lane l][8]:  W[64 w + 16 j + (l & 15)][32 s + 8 (l >> 4) + e]   (N = 512, K = 512)
 template <typename HT>
 __global__ __launch_bounds__(256) void gemm_stream_pack_kernel(const float* w, uint16_t* out) {
@@ -263,6 +431,46 @@ int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const floa
   // co-resident 32-row workgroups per CU at 12544 rows; a row's arithmetic does not depend on the tile height
   if (g_bf16_variant == 29) return launch_style_gemm<4>(g, src_fmt != 0, h16, s);
   return launch_style_gemm<2>(g, src_fmt != 0, h16, s);
+}
+
+// ---- fp32-grade form ---------------------------------------------------------------------------------------------------------
+int64_t gemm_stream3_elems(int N, int K) { return (N == SG_D && K == SG_D) ? 2 * (int64_t)N * K + 16 * 512 : 0; }
+
+int gemm_stream3_pack(const float* w, int N, int K, uint16_t* out, hipStream_t stream) {
+  if (!w || !out || N != SG_D || K != SG_D) return MDM_ERR_UNSUPPORTED;
+  if (hipMemsetAsync(out + 2 * (int64_t)N * K, 0, 16 * 512 * sizeof(uint16_t), stream) != hipSuccess) return MDM_ERR_LAUNCH;
+  hipLaunchKernelGGL(gemm_stream3_pack_kernel, dim3(128), dim3(256), 0, stream, w, out);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+template <int RT>
+static int launch_style_gemm3(const StyleGemmArgs& g, hipStream_t s) {
+  constexpr int smem = 16 * RT * SG_D * 4;  // hi | lo images = the fp32 staging of the epilogue
+  static DevOnce attr;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)style_gemm3_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return MDM_ERR_LAUNCH;
+    attr = true;
+  }
+  const dim3 grid((unsigned)((g.M + 16 * RT - 1) / (16 * RT)));
+  hipLaunchKernelGGL((style_gemm3_kernel<RT>), grid, dim3(SG_NT), smem, s, g);
+  MDM_RETURN_IF_LAUNCH_FAILED();
+  return MDM_OK;
+}
+
+// fp32 source rows, fp32 output; ws3 = the (hi, lo) pair stream of mdm_gemm_stream3_pack.  32-row tiles (two workgroups per CU) at
+// every size: 64-row tiles (one per CU, half the weight bytes per row; knob 58) measured 1 % of a step slower at the full time scale
+// (10.18 vs 10.06 ms) -- as in the 16-bit form, a second resident workgroup hides more than the halved stream saves.  A row's
+// arithmetic does not depend on the tile height.
+int style_gemm3(const float* src, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
+                const float* sc, const int* pos4, const uint16_t* ws3, const float* bias, const float* resid, float out_scale,
+                const float* colscale, float* out, hipStream_t s) {
+  if (M <= 0) return MDM_OK;
+  if (!style_gemm_supported(D, M)) return MDM_ERR_UNSUPPORTED;
+  if (!src || !sw || !sb || !sc || !ws3 || !bias || !out || S <= 0 || (pw && !pb) || ((uintptr_t)ws3 & 15)) return MDM_ERR_ARG;
+  const StyleGemmArgs g = {src, M, S, pw, pb, sw, sb, sc, pos4, ws3, bias, resid, out_scale, colscale, out, nullptr};
+  if (g_bf16_variant == 58) return launch_style_gemm3<4>(g, s);  // A/B knob: 64-row tiles
+  return launch_style_gemm3<2>(g, s);
 }
 
 }  // namespace mdm

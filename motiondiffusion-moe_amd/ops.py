@@ -199,6 +199,22 @@ def gemm_stream_pack(w: torch.Tensor, dtype: torch.dtype) -> Optional[torch.Tens
     return out
 
 
+def gemm_stream3_pack(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """(bf16 hi, lo) fragment-pair stream of one fp32 Linear [N, K] for the fp32-grade form of the fused stylization kernel
+    (csrc/style_gemm.hip style_gemm3); None when the shape is not taken (N = K = 512 only)."""
+    L.require_cuda(w)
+    N, K = w.shape
+    n = L.lib().mdm_gemm_stream3_elems(C.c_int32(N), C.c_int32(K))
+    if n <= 0:
+        return None
+    w = w.detach().to(torch.float32).contiguous()
+    out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(L.lib().mdm_gemm_stream3_pack(C.c_void_p(w.data_ptr()), C.c_int32(N), C.c_int32(K), C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(L.stream_ptr())), "mdm_gemm_stream3_pack")
+    return out
+
+
 def mlp_stream_pack_reference(w1: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """The same layout written as torch reshapes (tests check the packer kernel against it); csrc/mlp_stream.hip documents
     the order: per (group, wave)  W1(0) H0(0) | W1(1) H1(0) H0(1) | ... | W1(C-1) H1(C-2) H0(C-1) | H1(C-1)."""

@@ -205,6 +205,18 @@ class PackedModel:
                             ws = gemm_stream_pack(lay["W:" + st + "out"].to(dev), dt)
                             if ws is not None:
                                 self.wstream[st + "out"] = ws
+            # ... and its (hi, lo) pair streams for the fp32-grade form (csrc/style_gemm.hip style_gemm3): every format class whose
+            # stylization Linears are packed as bf16 hi + lo planes (fp32-grade and mixed runs)
+            if os.environ.get("MDM_MLP_STREAM", "1") != "0" and D == 512 and with_lo:
+                from .ops import gemm_stream3_pack
+                for li in range(2 * L_):
+                    k = f"L{li}."
+                    for st in (k + "local.style.", k + "global.style.", k + "ca_style.", k + "ffn_style."):
+                        if weight_format(st + "out", precision, head_dim) != "bf16x2":
+                            continue
+                        ws = gemm_stream3_pack(lay["W:" + st + "out"].to(dev))
+                        if ws is not None:
+                            self.wstream[st + "out3"] = ws
             self.layers = (L.Layer * (2 * L_))()
             for li, (pre, tag) in enumerate(layer_tags(L_)):
                 self._fill_layer(self.layers[li], f"L{li}.", pre, counters)
@@ -235,6 +247,8 @@ class PackedModel:
         st.out, st.out_b = self._packed(pre + "out"), self.V[pre + "out_b"].data_ptr()
         if (pre + "out") in self.wstream:
             st.out_ws = self.wstream[pre + "out"].data_ptr()
+        if (pre + "out3") in self.wstream:
+            st.out_ws3 = self.wstream[pre + "out3"].data_ptr()
 
     def _fill_layer(self, l: L.Layer, k: str, sd_prefix: str, counters):
         V, D = self.V, self.cfg["latent_dim"]

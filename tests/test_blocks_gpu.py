@@ -358,3 +358,30 @@ def test_fp32_grade_text_cross_attention_cores_in_one_launch(B, S, N, precision)
         print(f"block {block} B={B} S={S} N={N} precision={precision}: fused vs oracle {e_ref:.2e}, chain vs oracle {rel_inf(chain, ref):.2e}, fused vs chain {e_chain:.2e}")
         assert torch.isfinite(out).all()
         assert e_ref < 1e-3 and e_chain < 2e-4  # (the two paths may agree bit for bit: same split products, same k order)
+
+
+@pytest.mark.parametrize("precision", [3, 4])
+@pytest.mark.parametrize("B,S", [(2, 98), (3, 196), (1, 5), (5, 37), (2, 130)])
+def test_fp32_grade_stylization_in_one_launch(B, S, precision):
+    """csrc/style_gemm.hip style_gemm3: stylization input (post-norm / MoE combine / plain), its D x D Linear on bf16x3 products
+    with the (hi, lo) pair stream, and the residual in ONE launch, against the two launches it replaces (knob 60: style_in + GEMM) and
+    the oracle, through the blocks that end in a StylizationBlock; ragged last tiles."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, 6, precision)
+    L = pkg("_lib")
+    mask = R.src_mask(S, length)
+    with torch.no_grad():
+        trace = {}
+        refs = {L.BLOCK_DUAL: R.dual_self_attention(h, emb, mask, sd, pre + ".dual_self_attn", H, eph, proj, "low.0"),
+                L.BLOCK_CROSS: R.gated_cross_attention(h, xf, emb, sd, pre + ".cross_attn", H, eph["low.0.cross_style"]),
+                L.BLOCK_MOE: R.moe_ffn(h, emb, sd, pre + ".ffn", E, eph["low.0.ffn_style"], None, trace)}
+    for block, ref in refs.items():
+        out = _run_block(m, block, h, sc, length, xf)
+        L.lib().mdm_set_gemm_variant(60)
+        try:
+            two = _run_block(m, block, h, sc, length, xf)
+        finally:
+            L.lib().mdm_set_gemm_variant(0)
+        e_ref, e_two = rel_inf(out, ref), rel_inf(out, two)
+        print(f"block {block} B={B} S={S} precision={precision}: fused vs oracle {e_ref:.2e}, two launches vs oracle {rel_inf(two, ref):.2e}, fused vs two {e_two:.2e}")
+        assert torch.isfinite(out).all()
+        assert e_ref < 1e-3 and e_two < 2e-4
