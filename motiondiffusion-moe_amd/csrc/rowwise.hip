@@ -824,17 +824,18 @@ int style_in(const float* x, int64_t M, int D, int S, const float* pw, const flo
 // tests/test_blocks_gpu.py, tests/test_bigsize_gpu.py); knob 26 takes it wherever it exists, knob 27 never.
 bool gate16_const_wanted(int nv, int E) {
   if (g_bf16_variant == 27) return false;
-  return g_bf16_variant == 26 || ((nv == 8 || nv == 16) && E == 8);
+  // E = 16 (BASELINE configs[4]) as well: 6.65 -> 6.50 ms per step at its per-GPU shape (big, B = 8), same-box A/B of knobs 0 / 26
+  return g_bf16_variant == 26 || ((nv == 8 || nv == 16) && (E == 8 || E == 16));
 }
-template <int NV, int EX, int HNF>
+template <int NV, int EX, int HNF, bool FAST = true>
 bool launch_gate16_const(int grid, int smem, hipStream_t s, const float* x, int64_t M, int D, int E, const MoeGateParams& p) {
   static DevInt attr_done;
   if (smem > 65536 && smem > attr_done) {
-    if (hipFuncSetAttribute((const void*)moe_gate16_kernel<NV, true, EX, HNF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)moe_gate16_kernel<NV, FAST, EX, HNF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return false;
     attr_done = smem;
   }
-  hipLaunchKernelGGL((moe_gate16_kernel<NV, true, EX, HNF>), dim3(grid), dim3(256), smem, s, x, M, D, E, p);
+  hipLaunchKernelGGL((moe_gate16_kernel<NV, FAST, EX, HNF>), dim3(grid), dim3(256), smem, s, x, M, D, E, p);
   return true;
 }
 template <int NV, int EX>
@@ -842,6 +843,11 @@ bool gate16_const_fmt(int grid, int smem, hipStream_t s, const float* x, int64_t
   switch (p.hn_bf16) {
     case 1: return launch_gate16_const<NV, EX, 1>(grid, smem, s, x, M, D, E, p);
     case 2: return launch_gate16_const<NV, EX, 2>(grid, smem, s, x, M, D, E, p);
+    // fp32 rows (the fp32-grade modes): straight-line code as well, with the sum-of-products association of the logits that
+    // those modes' routing is pinned to (FAST = false): bit-identical to the run-time-E kernel
+    case 0:
+      if constexpr (NV == 8 && EX == 8) return launch_gate16_const<NV, EX, 0, false>(grid, smem, s, x, M, D, E, p);
+      return false;
     default: return false;  // fp8 rows are written after the logit loop: nothing per chunk pins the FMAs, and they sink again
   }
 }

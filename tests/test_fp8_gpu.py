@@ -173,3 +173,30 @@ def test_configs4_big_16_experts_fp8_mode_error_and_flips(Ln, T):
     else:
         assert res[5][5] < FP8_FORCED_MEDIAN_BUDGET and res[5][2] <= 0.40 * res[5][3]
     assert res[2][1] < 8e-3 and res[2][2] <= 0.03 * res[2][3]
+
+
+@pytest.mark.parametrize("precision", [2, 5])
+def test_sixteen_expert_router_with_compile_time_expert_count_is_bit_identical(precision):
+    """E = 16, D = 1024 (BASELINE configs[4]): the router instantiated for the expert count and hn format (the default since round
+    4, knob 26) against the run-time one (knob 27) through a whole forward at a ragged batch: same arithmetic in the same order, so
+    bit-equal outputs (the fp8 rows are written after the logit loop and keep the run-time kernel: equal trivially)."""
+    T_, synth = pkg("transformer"), pkg("synth")
+    B, T, Ln, E = 3, 38, 1, 16
+    m = T_.MotionTransformer(263, num_frames=196, latent_dim=512, ff_size=1024, num_layers=Ln, num_heads=4, text_latent_dim=256,
+                             moe_num_experts=E, model_size="big", precision=precision)
+    m.load_state_dict(synth.synth_state_dict(m._layout, 4), strict=True)
+    m.set_ephemerals(synth.synth_ephemerals(1024, 512, Ln, 7)), m.set_projections(synth.synth_projections(256, Ln, 7))
+    m = m.cuda().eval()
+    x, _, length, xf_proj, xf_out = synth.synth_inputs(B, T, 263, 28, 512, 0, min_len=8)
+    t = torch.full((B,), 500, dtype=torch.int64)
+    lib = pkg("_lib").lib()
+    outs = {}
+    for knob in (27, 26, 0):
+        lib.mdm_set_gemm_variant(knob)
+        try:
+            outs[knob] = m(x.cuda(), t.cuda(), length.cuda(), xf_proj=xf_proj.cuda(), xf_out=xf_out.cuda()).cpu()
+        finally:
+            lib.mdm_set_gemm_variant(0)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[26], outs[27]), float((outs[26] - outs[27]).abs().max())
+    assert torch.equal(outs[0], outs[27])
