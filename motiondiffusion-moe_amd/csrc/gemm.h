@@ -94,9 +94,17 @@ bool style_gemm_supported(int D, int64_t M);
 // fp32-grade form: fp32 source rows, bf16x3 products, (hi, lo) fragment pair stream
 int64_t gemm_stream3_elems(int N, int K);
 int gemm_stream3_pack(const float* w, int N, int K, uint16_t* out, hipStream_t stream);
+// what style_gemm3 may do with the finished row r while it is on chip (all optional; see StyleGemmArgs in csrc/style_gemm.hip)
+struct StyleTail3 {
+  const float *lw = nullptr, *lb = nullptr;  // skip == NULL: ln_out = LN(r; lw, lb);  else out = LN(skip + skip_scale * r; lw, lb)
+  float* ln_out = nullptr;                   // fp32 [M, D]
+  const float* skip = nullptr;               // [M, D] fp32
+  float skip_scale = 0.f;
+  const float *l2w = nullptr, *l2b = nullptr;  // with skip: ln_out = LN(out; l2w, l2b)
+};
 int style_gemm3(const float* src, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
                 const float* sc, const int* pos4, const uint16_t* ws3, const float* bias, const float* resid, float out_scale,
-                const float* colscale, float* out, hipStream_t s);
+                const float* colscale, float* out, const StyleTail3& t, hipStream_t s);
 int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
                const float* sc, const int* pos4, const uint16_t* ws, const float* bias, const float* resid, float out_scale,
                const float* colscale, float* out, uint16_t* out16, int h16, hipStream_t s);

@@ -182,16 +182,22 @@ int linear_to_act(const Ctx& c, Act A, int64_t M, int K, const MdmPacked& W, con
 }
 
 // out = resid + out_scale * colscale * Lin(SiLU(LN(a)(1+scale)+shift)) with a = [post-processed] src
+// t3 / t3_done: fp32-grade modes only -- what the fused launch may do with the finished rows (csrc/gemm.h StyleTail3); *t3_done says
+// whether it did (false: the caller runs those LayerNorms itself)
 int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float* pw, const float* pb, const int* pos4,
                 const float* sc, float* tmp, const float* resid, float out_scale, const float* colscale, float* out,
-                uint16_t* out16 = nullptr, bool src_bf16 = false) {
+                uint16_t* out16 = nullptr, bool src_bf16 = false, const StyleTail3* t3 = nullptr, bool* t3_done = nullptr) {
   const int D = c.m->D;
   if (c.bf && st.out_ws && g_bf16_variant != 30 && style_gemm_supported(D, c.M))  // one launch (csrc/style_gemm.hip); knob 30: two
     return style_gemm(src, src_bf16 ? c.h16 : 0, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, st.out_ws, st.out_b, resid,
                       out_scale, colscale, out, out16, c.h16, c.s);
   // fp32-grade modes: the same fusion on bf16x3 products (csrc/style_gemm.hip style_gemm3; knob 60: two launches)
-  if (!c.bf && c.prec == 3 && !src_bf16 && !out16 && st.out_ws3 && g_bf16_variant != 60 && style_gemm_supported(D, c.M))
-    return style_gemm3(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, st.out_ws3, st.out_b, resid, out_scale, colscale, out, c.s);
+  if (!c.bf && c.prec == 3 && !src_bf16 && !out16 && st.out_ws3 && g_bf16_variant != 60 && style_gemm_supported(D, c.M)) {
+    const bool tail = t3 && g_bf16_variant != 61;  // knob 61: the LayerNorms behind it as their own launches
+    if (t3_done) *t3_done = tail;
+    return style_gemm3(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, st.out_ws3, st.out_b, resid, out_scale, colscale, out,
+                       tail ? *t3 : StyleTail3(), c.s);
+  }
   MDM_TRY(style_in(src, c.M, D, c.S, pw, pb, st.norm_w, st.norm_b, sc, pos4, src_bf16 ? c.h16 : 0, tmp, fmt16(c), c.s));
   LinOpts o;
   o.out_scale = out_scale, o.R1 = resid, o.colscale = colscale;
@@ -206,6 +212,7 @@ int style_apply(const Ctx& c, const MdmStyle& st, const float* src, const float*
 struct PerfTail {
   const float *lw = nullptr, *lb = nullptr;
   uint16_t* ln16 = nullptr;
+  float* ln32 = nullptr;  // the fp32-grade modes' form of ln16 (fp32 rows; csrc/style_gemm.hip style_gemm3)
   const float* skip = nullptr;
   float skip_scale = 0.f;
   const float *l2w = nullptr, *l2b = nullptr;
@@ -347,7 +354,16 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, p.proj0, p.proj0_b, D, w.t2, o));
     MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, p.proj3, p.proj3_b, D, t16 ? nullptr : w.t4, t16 ? (uint16_t*)w.t4 : nullptr));
   }
-  // post_norm, normalize * sqrt(D), stylization, y = x + 0.1 * style (:169-178)
+  // post_norm, normalize * sqrt(D), stylization, y = x + 0.1 * style (:169-178); fp32-grade modes: the caller's LayerNorms / block
+  // tail behind it in the same launch when it asks for them (pt.ln32 / pt.skip)
+  if (!c.bf && (pt.ln32 || pt.skip)) {
+    StyleTail3 t3;
+    t3.lw = pt.lw, t3.lb = pt.lb, t3.ln_out = pt.ln32, t3.skip = pt.skip, t3.skip_scale = pt.skip_scale, t3.l2w = pt.l2w, t3.l2b = pt.l2b;
+    bool did = false;
+    MDM_TRY(style_apply(c, p.style, w.t4, p.post_w, p.post_b, nullptr, sc, w.t2, x, 0.1f, nullptr, out, nullptr, t16, &t3, &did));
+    if (pt.done) *pt.done = did;
+    return MDM_OK;
+  }
   return style_apply(c, p.style, w.t4, p.post_w, p.post_b, nullptr, sc, w.t2, x, 0.1f, nullptr, out, nullptr, t16);
 }
 
@@ -364,11 +380,14 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
   // launch ends with out = post_norm(skip + 0.1 * global_out) and the next block's pre-norm -- no D x D GEMM waiting behind the
   // attention chain, no LayerNorm launch behind that.
   const bool tails = performer_tail_fused(c, l.local) && performer_tail_fused(c, l.global);
+  // fp32-grade modes: the same re-ordering with the tails inside the stylization launches (style_gemm3): knobs 60 / 61 undo it
+  const bool tails3 = !c.bf && c.prec == 3 && g_bf16_variant != 60 && g_bf16_variant != 61 && l.local.style.out_ws3 &&
+                      l.global.style.out_ws3 && style_gemm_supported(D, c.M);
   float* const skipbuf = w.f1;
-  if (tails) {
+  if (tails || tails3) {
     LinOpts o;
     o.act = ACT_GELU;
-    MDM_TRY(linear(c, act_bf16(x16), c.M, D, l.skip, l.skip_b, D, skipbuf, nullptr, o));
+    MDM_TRY(linear(c, tails ? act_bf16(x16) : act_f32(x), c.M, D, l.skip, l.skip_b, D, skipbuf, nullptr, o));
   }
   // h = pre_norm(x) -> t1 ; local.pre_norm(h) -> t3
   MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, 0, l.local.pre_w, l.local.pre_b, w.t3, fmt16(c), c.s));
@@ -376,14 +395,16 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
   {
     PerfTail pt;
     if (c.bf) pt.lw = l.global.pre_w, pt.lb = l.global.pre_b, pt.ln16 = (uint16_t*)w.t3, pt.done = &normed;
+    if (tails3) pt.lw = l.global.pre_w, pt.lb = l.global.pre_b, pt.ln32 = w.t3, pt.done = &normed;
     MDM_TRY(performer(c, l.local, w.t1, act_of(c, w.t3), sc4 + 0 * scs, w.t5, pt));
   }
   if (!normed) MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
-  if (tails && normed) {
+  if ((tails || tails3) && normed) {
     bool done = false;
     PerfTail pt;
     pt.skip = skipbuf, pt.skip_scale = 0.1f, pt.lw = l.dual_post_w, pt.lb = l.dual_post_b, pt.done = &done;
-    if (next_w) pt.l2w = next_w, pt.l2b = next_b, pt.ln16 = (uint16_t*)w.t2;
+    if (next_w && tails) pt.l2w = next_w, pt.l2b = next_b, pt.ln16 = (uint16_t*)w.t2;
+    if (next_w && tails3) pt.l2w = next_w, pt.l2b = next_b, pt.ln32 = w.t2;
     MDM_TRY(performer(c, l.global, w.t5, act_of(c, w.t3), sc4 + 1 * scs, out, pt));
     if (done) return MDM_OK;
     return MDM_ERR_LAUNCH;  // (unreachable: performer_tail_fused said the tail runs)

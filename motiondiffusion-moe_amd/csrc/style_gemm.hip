@@ -46,6 +46,15 @@ struct StyleGemmArgs {
   const float* colscale;  // optional [D]
   float* out;
   uint16_t* out16;      // optional 16-bit copy
+  // fp32-grade form only (style_gemm3): what may follow the row while it is still on chip.  With r = resid + out_scale * colscale * (...)
+  //   skip == NULL: out = r;  ln_out = LN(r; lw, lb) when lw is set                  (the pre-norm of the block that follows)
+  //   skip != NULL: out = LN(skip + skip_scale * r; lw, lb)  (r itself is not written);  ln_out = LN(out; l2w, l2b) when l2w is set
+  //                 (the tail of DualSelfAttentionBlock behind its second Performer, fast_attention.py:219-225)
+  const float *lw, *lb;
+  float* ln_out;
+  const float* skip;
+  float skip_scale;
+  const float *l2w, *l2b;
 };
 
 template <typename HT, bool SRC16, int SG_RT>
@@ -333,18 +342,50 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm3_kerne
     }
   }
   sg_barrier();
-  const int cl = tid & 127, n = 4 * cl;
+  {
+    // one wave per row (lane: columns 4 l .. 4 l + 3 and 256 + 4 l ..): the residual / skip operands of the wave's rows are all
+    // requested first (one memory round trip per wave), then row by row: residual, optional block tail and LayerNorms, stores
+    R8 xr[RPW], sk[RPW];
 #pragma unroll
-  for (int k = 0; k < SG_ROWS / 4; ++k) {
-    const int ml = (tid >> 7) + 4 * k;
-    const int64_t m = row0 + ml;
-    if (m >= g.M) continue;
-    f32x4 v = *(const f32x4*)(stg + ml * D + ((cl ^ (ml & 31)) << 2));
-    if (g.resid) {
-      const f32x4 q = *(const f32x4*)(g.resid + m * D + n);
-      v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
+    for (int q = 0; q < RPW; ++q) {
+      int64_t m = row0 + RPW * wn + q;
+      m = m < g.M ? m : g.M - 1;
+      if (g.resid) xr[q].load(g.resid + m * D, D, lane);
+      if (g.skip) sk[q].load(g.skip + m * D, D, lane);
     }
-    *(f32x4*)(g.out + m * D + n) = v;
+    R8 lww, lbb, l2ww, l2bb;
+    if (g.lw) lww.load(g.lw, D, lane), lbb.load(g.lb, D, lane);
+    if (g.l2w) l2ww.load(g.l2w, D, lane), l2bb.load(g.l2b, D, lane);
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+      const int rl = RPW * wn + q;
+      const int64_t m = row0 + rl;
+      if (m >= g.M) continue;  // (wave-uniform)
+      const f32x4 v0 = *(const f32x4*)(stg + rl * D + ((lane ^ (rl & 31)) << 2));
+      const f32x4 v1 = *(const f32x4*)(stg + rl * D + (((64 + lane) ^ (rl & 31)) << 2));
+      R8 r;
+      r.e[0] = v0[0], r.e[1] = v0[1], r.e[2] = v0[2], r.e[3] = v0[3], r.e[4] = v1[0], r.e[5] = v1[1], r.e[6] = v1[2], r.e[7] = v1[3];
+      if (g.resid) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.e[j] += xr[q].e[j];
+      }
+      if (g.skip) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.e[j] = sk[q].e[j] + g.skip_scale * r.e[j];
+        r.layernorm(lww, lbb, D, lane);
+        r.store(g.out + m * D, D, lane);
+        if (g.l2w) {
+          r.layernorm(l2ww, l2bb, D, lane);
+          r.store(g.ln_out + m * D, D, lane);
+        }
+      } else {
+        r.store(g.out + m * D, D, lane);
+        if (g.lw) {
+          r.layernorm(lww, lbb, D, lane);
+          r.store(g.ln_out + m * D, D, lane);
+        }
+      }
+    }
   }
 }
 
@@ -426,7 +467,9 @@ int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const floa
   if (!style_gemm_supported(D, M)) return MDM_ERR_UNSUPPORTED;
   if (!src || !sw || !sb || !sc || !ws || !bias || !out || S <= 0 || (pw && !pb)) return MDM_ERR_ARG;
   if ((h16 != MDM_H16_BF16 && h16 != MDM_H16_F16) || (src_fmt != 0 && src_fmt != h16) || ((uintptr_t)ws & 15)) return MDM_ERR_ARG;
-  const StyleGemmArgs g = {src, M, S, pw, pb, sw, sb, sc, pos4, ws, bias, resid, out_scale, colscale, out, out16};
+  StyleGemmArgs g = {};
+  g.src = src, g.M = M, g.S = S, g.pw = pw, g.pb = pb, g.sw = sw, g.sb = sb, g.sc = sc, g.pos4 = pos4, g.ws = ws, g.bias = bias;
+  g.resid = resid, g.out_scale = out_scale, g.colscale = colscale, g.out = out, g.out16 = out16;
   // knob 29: 64-row tiles (one workgroup per CU, half the weight bytes per row) -- measured 1 % of a step SLOWER than two
   // co-resident 32-row workgroups per CU at 12544 rows; a row's arithmetic does not depend on the tile height
   if (g_bf16_variant == 29) return launch_style_gemm<4>(g, src_fmt != 0, h16, s);
@@ -464,11 +507,16 @@ static int launch_style_gemm3(const StyleGemmArgs& g, hipStream_t s) {
 // arithmetic does not depend on the tile height.
 int style_gemm3(const float* src, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
                 const float* sc, const int* pos4, const uint16_t* ws3, const float* bias, const float* resid, float out_scale,
-                const float* colscale, float* out, hipStream_t s) {
+                const float* colscale, float* out, const StyleTail3& t, hipStream_t s) {
   if (M <= 0) return MDM_OK;
   if (!style_gemm_supported(D, M)) return MDM_ERR_UNSUPPORTED;
   if (!src || !sw || !sb || !sc || !ws3 || !bias || !out || S <= 0 || (pw && !pb) || ((uintptr_t)ws3 & 15)) return MDM_ERR_ARG;
-  const StyleGemmArgs g = {src, M, S, pw, pb, sw, sb, sc, pos4, ws3, bias, resid, out_scale, colscale, out, nullptr};
+  if ((t.lw && !t.lb) || (t.skip && (!t.lw || !t.lb)) || (t.l2w && (!t.l2b || !t.skip)) || ((t.skip ? t.l2w != nullptr : t.lw != nullptr) != (t.ln_out != nullptr)))
+    return MDM_ERR_ARG;
+  StyleGemmArgs g = {};
+  g.src = src, g.M = M, g.S = S, g.pw = pw, g.pb = pb, g.sw = sw, g.sb = sb, g.sc = sc, g.pos4 = pos4, g.ws = ws3, g.bias = bias;
+  g.resid = resid, g.out_scale = out_scale, g.colscale = colscale, g.out = out;
+  g.lw = t.lw, g.lb = t.lb, g.ln_out = t.ln_out, g.skip = t.skip, g.skip_scale = t.skip_scale, g.l2w = t.l2w, g.l2b = t.l2b;
   if (g_bf16_variant == 58) return launch_style_gemm3<4>(g, s);  // A/B knob: 64-row tiles
   return launch_style_gemm3<2>(g, s);
 }
