@@ -23,7 +23,12 @@ extern "C" {
 #endif
 
 enum { MDM_OK = 0, MDM_ERR_ARG = 1, MDM_ERR_LAUNCH = 2, MDM_ERR_UNSUPPORTED = 3 };
-enum { MDM_OP_F32_ROW = 0, MDM_OP_F32_KSTRIDE = 1, MDM_OP_BF16_ROW = 2, MDM_OP_FP8_ROW = 3 /* e4m3 bytes, csrc/gemm8.hip */ };
+enum { MDM_OP_F32_ROW = 0, MDM_OP_F32_KSTRIDE = 1, MDM_OP_BF16_ROW = 2, MDM_OP_FP8_ROW = 3 /* e4m3 bytes, csrc/gemm8.hip */,
+       /* activation rows PRE-SPLIT for the fp32-grade kernel (csrc/gemm3.hip): per row and per block of 32 k, 32 bf16 "hi" then 32
+        * bf16 "lo" = rn(x - hi) -- 128 bytes, exactly the bytes of the 32 fp32 values they replace, so `ld` (in 4-byte units, as for
+        * MDM_OP_F32_ROW) and every buffer size stay what they are for fp32 rows.  Written by the producers (MdmGemmDesc.Cx2 and the
+        * row-wise / attention kernels) so that the GEMM's K loop does not re-split each fp32 fragment in every wave that reads it */
+       MDM_OP_X2_ROW = 4 };
 enum { MDM_ACT_NONE = 0, MDM_ACT_GELU = 1, MDM_ACT_SILU = 2, MDM_ACT_FEAT = 3,
        /* fp32-grade kernel only (precision 3, N % 128 == 0): every 128-column slice of a row is one attention head --
         * LayerNorm over the slice with hn_w / hn_b (eps 1e-5), L2-normalised when the slice index is < hn_l2_tiles
@@ -103,6 +108,8 @@ typedef struct MdmGemmDesc {
   const float* hn_b;
   uint16_t* C16_lo;
   int32_t hn_l2_tiles;
+  /* fp32-grade kernel: the result as MDM_OP_X2_ROW rows (row stride 2 * ldc 16-bit elements; N % 32 == 0), beside or instead of C */
+  uint16_t* Cx2;
 } MdmGemmDesc;
 
 int mdm_gemm(const MdmGemmDesc* desc, void* stream);

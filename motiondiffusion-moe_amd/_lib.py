@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDM_LIB") or os.path.join(_HERE, "libmdm_hip.so")  # MDM_LIB: A/B benchmarking of builds
 _lib = None
 
-OP_F32_ROW, OP_F32_KSTRIDE, OP_BF16_ROW, OP_FP8_ROW = 0, 1, 2, 3
+OP_F32_ROW, OP_F32_KSTRIDE, OP_BF16_ROW, OP_FP8_ROW, OP_X2_ROW = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_FEAT, ACT_HEADNORM, ACT_HEADSOFTMAX = 0, 1, 2, 3, 4, 5
 H16_BF16, H16_F16 = 1, 2  # MDM_H16_*
 PREC_BF16, PREC_F16, PREC_X3, PREC_MIXED, PREC_FP8 = 1, 2, 3, 4, 5  # MDM_PREC_*
@@ -41,7 +41,7 @@ class GemmDesc(C.Structure):
                 ("feat_rpt", C.c_int32), ("feat_kslot", C.c_int32), ("precision", C.c_int32), ("h16", C.c_int32),
                 ("a_scale", C.c_void_p), ("w_scale", C.c_void_p), ("a_scale_u", C.c_float), ("C8", C.c_void_p),
                 ("c8_scale", C.c_float), ("kgoff", C.c_void_p), ("hn_w", C.c_void_p), ("hn_b", C.c_void_p),
-                ("C16_lo", C.c_void_p), ("hn_l2_tiles", C.c_int32)]
+                ("C16_lo", C.c_void_p), ("hn_l2_tiles", C.c_int32), ("Cx2", C.c_void_p)]
 
 
 class MoeTensors(C.Structure):

@@ -11,7 +11,7 @@ namespace mdm {
 typedef MdmOperand Operand;
 typedef MdmGemmDesc GemmArgs;
 
-enum OperandKind { OP_F32_ROW = MDM_OP_F32_ROW, OP_F32_KSTRIDE = MDM_OP_F32_KSTRIDE, OP_BF16_ROW = MDM_OP_BF16_ROW };
+enum OperandKind { OP_F32_ROW = MDM_OP_F32_ROW, OP_F32_KSTRIDE = MDM_OP_F32_KSTRIDE, OP_BF16_ROW = MDM_OP_BF16_ROW, OP_X2_ROW = MDM_OP_X2_ROW };
 enum Act { ACT_NONE = MDM_ACT_NONE, ACT_GELU = MDM_ACT_GELU, ACT_SILU = MDM_ACT_SILU, ACT_FEAT = MDM_ACT_FEAT, ACT_HEADNORM = MDM_ACT_HEADNORM, ACT_HEADSOFTMAX = MDM_ACT_HEADSOFTMAX };
 
 inline GemmArgs gemm_defaults(int precision) {
@@ -101,6 +101,7 @@ struct StyleTail3 {
   const float* skip = nullptr;               // [M, D] fp32
   float skip_scale = 0.f;
   const float *l2w = nullptr, *l2b = nullptr;  // with skip: ln_out = LN(out; l2w, l2b)
+  int ln_x2 = 0;                               // ln_out as MDM_OP_X2_ROW rows instead of fp32
 };
 int style_gemm3(const float* src, int64_t M, int D, int S, const float* pw, const float* pb, const float* sw, const float* sb,
                 const float* sc, const int* pos4, const uint16_t* ws3, const float* bias, const float* resid, float out_scale,

@@ -371,7 +371,7 @@ int gemm(const GemmArgs& a_in, hipStream_t stream) {
     if (a.c8_scale == 0.f) a.c8_scale = 1.f;
     return gemm_fp8(a, stream);
   }
-  if (a.K <= 0 || !a.A.p || !a.W.p || (!a.C && !a.C16)) return MDM_ERR_ARG;
+  if (a.K <= 0 || !a.A.p || !a.W.p || (!a.C && !a.C16 && !a.Cx2)) return MDM_ERR_ARG;
   if (a.A.kind == OP_BF16_ROW) return gemm_bf16(a, stream);  // bf16 activations: throughput kernel (gemm2.hip)
   if (a.precision != 1 && a.precision != 3) return MDM_ERR_ARG;
   if (a.W.kind == OP_BF16_ROW) {
@@ -383,8 +383,10 @@ int gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.goff && (a.batch != 1 || a.ngroups <= 0)) return MDM_ERR_ARG;
   if (a.kgoff && (a.goff || a.A.kind != OP_F32_KSTRIDE || a.W.kind != OP_F32_KSTRIDE)) return MDM_ERR_ARG;
   // plain Linears of the fp32-grade mode: LDS-DMA staged bf16x3 kernel (gemm3.hip); knob 36 keeps the register-staged one
-  if ((g_bf16_variant != 36 || a.act == ACT_HEADNORM || a.act == ACT_HEADSOFTMAX || a.C16_lo) && gemm_x3_dma_eligible(a)) return gemm_x3_dma(a, stream);
-  if (a.C16_lo) return MDM_ERR_UNSUPPORTED;  // plane outputs exist on that kernel only
+  if ((g_bf16_variant != 36 || a.act == ACT_HEADNORM || a.act == ACT_HEADSOFTMAX || a.C16_lo || a.Cx2 || a.A.kind == OP_X2_ROW) &&
+      gemm_x3_dma_eligible(a))
+    return gemm_x3_dma(a, stream);
+  if (a.C16_lo || a.Cx2 || a.A.kind == OP_X2_ROW) return MDM_ERR_UNSUPPORTED;  // pre-split rows / plane outputs exist on that kernel only
   const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
   const int tn = (a.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)a.batch);

@@ -36,7 +36,11 @@ __device__ __forceinline__ void wait_vm3() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN3, int NSTAGE, int ACT>
+// AX2: the activation rows arrive pre-split (MDM_OP_X2_ROW: per row and 32-k block 64 B of hi + 64 B of lo, the same 128 bytes and the
+// same LDS-DMA pattern as the fp32 block): the fragment is two reads and NO arithmetic.  Splitting fp32 fragments in the loop costs
+// 11 - 18 % of the kernel (24 VALU instructions per fragment in every wave that reads it: a timing build without them ran 30.1 vs
+// 33.8 us at 12544 x 512 x 512 and 166 vs 202 us at the expert W1 shape), and the same row is re-split by every column tile.
+template <int BM, int BN3, int NSTAGE, int ACT, bool AX2>
 __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
   constexpr int NWN = BN3 / 64, NW = 2 * NWN, NT3 = 64 * NW;
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
@@ -172,15 +176,21 @@ __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int ra = wm * (BM / 2) + i * 16 + frow;
-      const f32x4 x0 = *(const f32x4*)(sa + ra * 128 + (((2 * fq) ^ (ra & 7)) << 4));
-      const f32x4 x1 = *(const f32x4*)(sa + ra * 128 + (((2 * fq + 1) ^ (ra & 7)) << 4));
-      uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
-      split_bf16(x0[0], x0[1], h0, l0);
-      split_bf16(x0[2], x0[3], h1, l1);
-      split_bf16(x1[0], x1[1], h2, l2);
-      split_bf16(x1[2], x1[3], h3, l3);
-      const u32x4_3 uh = {h0, h1, h2, h3}, ul = {l0, l1, l2, l3};
-      const frag3_t ah = __builtin_bit_cast(frag3_t, uh), al = __builtin_bit_cast(frag3_t, ul);
+      frag3_t ah, al;
+      if constexpr (AX2) {  // hi k = 8 fq .. 8 fq + 7 = 16-B chunk fq of the row's 128 bytes, lo = chunk 4 + fq (conflict-free as well)
+        ah = *(const frag3_t*)(sa + ra * 128 + ((fq ^ (ra & 7)) << 4));
+        al = *(const frag3_t*)(sa + ra * 128 + (((4 + fq) ^ (ra & 7)) << 4));
+      } else {
+        const f32x4 x0 = *(const f32x4*)(sa + ra * 128 + (((2 * fq) ^ (ra & 7)) << 4));
+        const f32x4 x1 = *(const f32x4*)(sa + ra * 128 + (((2 * fq + 1) ^ (ra & 7)) << 4));
+        uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+        split_bf16(x0[0], x0[1], h0, l0);
+        split_bf16(x0[2], x0[3], h1, l1);
+        split_bf16(x1[0], x1[1], h2, l2);
+        split_bf16(x1[2], x1[3], h3, l3);
+        const u32x4_3 uh = {h0, h1, h2, h3}, ul = {l0, l1, l2, l3};
+        ah = __builtin_bit_cast(frag3_t, uh), al = __builtin_bit_cast(frag3_t, ul);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {  // D = W A^T; small terms first, as gemm.hip does
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
             v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
           }
           if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;
+          if (g.Cx2) store_x2_4(g.Cx2 + (int64_t)m * 2 * g.ldc, n, v[0], v[1], v[2], v[3]);  // pre-split rows for the next GEMM
           if (g.C16_lo) {  // bf16 hi / lo planes (the operand format of the fp32-grade attention cores)
             uint32_t h0, h1, l0, l1;
             split_bf16(v[0], v[1], h0, l0);
@@ -310,22 +321,26 @@ __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
   }
 }
 
-template <int BM, int BN, int NS, int ACT>
-int launch3_act(const GemmArgs& a, hipStream_t stream) {
+template <int BM, int BN, int NS, int ACT, bool AX2>
+int launch3_k(const GemmArgs& a, hipStream_t stream) {
   constexpr int ring = NS * (BM * 128 + 2 * BN * 64), stgb = (BM * BN * 4 > 128 * 1024) ? BM * BN * 2 : BM * BN * 4;
   constexpr int smem = ring > stgb ? ring : stgb;
   static_assert(smem <= 160 * 1024, "LDS");
   static DevOnce attr;
   if (smem > 65536 && !attr) {
-    if (hipFuncSetAttribute((const void*)gemm_x3_kernel<BM, BN, NS, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_x3_kernel<BM, BN, NS, ACT, AX2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return MDM_ERR_LAUNCH;
     attr = true;
   }
   const int tm = (a.M + BM - 1) / BM + (a.goff ? a.ngroups : 0);
   const int tn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, NS, ACT>), dim3((unsigned)(tm * tn)), dim3(2 * BN), smem, stream, a);
+  hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, NS, ACT, AX2>), dim3((unsigned)(tm * tn)), dim3(2 * BN), smem, stream, a);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;
+}
+template <int BM, int BN, int NS, int ACT>
+int launch3_act(const GemmArgs& a, hipStream_t stream) {
+  return a.A.kind == OP_X2_ROW ? launch3_k<BM, BN, NS, ACT, true>(a, stream) : launch3_k<BM, BN, NS, ACT, false>(a, stream);
 }
 template <int BM, int BN, int NS>
 int launch3(const GemmArgs& a, hipStream_t stream) {
@@ -344,7 +359,7 @@ int launch3(const GemmArgs& a, hipStream_t stream) {
 extern int g_bf16_variant;
 
 bool gemm_x3_dma_eligible(const GemmArgs& a) {
-  const bool base = a.precision == 3 && a.A.kind == OP_F32_ROW && a.W.kind == OP_BF16_ROW && a.W.p_lo && a.batch == 1 && a.A.rpg == 0 &&
+  const bool base = a.precision == 3 && (a.A.kind == OP_F32_ROW || a.A.kind == OP_X2_ROW) && a.W.kind == OP_BF16_ROW && a.W.p_lo && a.batch == 1 && a.A.rpg == 0 &&
                     a.K >= 32 && (a.K % 32) == 0 && (a.A.ld % 4) == 0 && (a.W.ld % 8) == 0 && (a.W.bs1 % 8) == 0 &&
                     ((((uintptr_t)a.A.p) | ((uintptr_t)a.W.p) | ((uintptr_t)a.W.p_lo)) & 15) == 0 && a.M >= 1;
   if (!base) return false;
@@ -352,6 +367,9 @@ bool gemm_x3_dma_eligible(const GemmArgs& a) {
   const bool planes_ok = a.C16 && a.C16_lo && !a.C && a.N % 128 == 0 && (a.ldc % 4) == 0 && (!a.R1 || (a.ldr1 & 3) == 0) &&
                          (!a.R2 || (a.ldr2 & 3) == 0) && ((((uintptr_t)a.C16) | ((uintptr_t)a.C16_lo)) & 7) == 0;
   if (a.C16_lo && !planes_ok) return false;
+  if (a.Cx2 && ((a.N % 32) || (a.ldc % 4) || (((uintptr_t)a.Cx2) & 7) || (a.R1 && (a.ldr1 & 3)) || (a.R2 && (a.ldr2 & 3)) ||
+                a.act == ACT_HEADNORM || a.act == ACT_HEADSOFTMAX))
+    return false;
   if (a.act == ACT_HEADNORM)
     return planes_ok && a.hn_w && a.hn_b && !a.R1 && !a.R2 && !a.goff && ((((uintptr_t)a.hn_w) | ((uintptr_t)a.hn_b)) & 15) == 0;
   if (a.act == ACT_HEADSOFTMAX) return planes_ok && !a.R1 && !a.R2 && !a.goff;
@@ -360,7 +378,7 @@ bool gemm_x3_dma_eligible(const GemmArgs& a) {
 
 int gemm_x3_dma(const GemmArgs& a, hipStream_t stream) {
   if (!gemm_x3_dma_eligible(a)) return MDM_ERR_UNSUPPORTED;
-  if (!a.C && !a.C16) return MDM_ERR_ARG;
+  if (!a.C && !a.C16 && !a.Cx2) return MDM_ERR_ARG;
   const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const bool small = !a.goff && (tiles128 <= 256 || a.M <= 64);
   if (g_bf16_variant == 37) return launch3<128, 128, 3>(a, stream);  // A/B knobs: ring depth at the 128-row tile

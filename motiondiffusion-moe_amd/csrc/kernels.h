@@ -57,14 +57,15 @@ int perf_attn256(const void* qkv, int h16, const uint16_t* PT, int ldp, const fl
 // q | k | v rows after LayerNorm(dh) and the L2 normalisation of q, k (the projection GEMM's ACT_HEADNORM epilogue), ph / pl =
 // planes of P^T [128][ldp]; out fp32 [B S, D]
 bool perf_attn3_supported(int dh, int S);
+// out_x2: the output rows pre-split for the GEMM that follows (MDM_OP_X2_ROW) instead of fp32
 int perf_attn3(const uint16_t* xh, const uint16_t* xl, const uint16_t* ph, const uint16_t* pl, int ldp, const float* hn_w,
-               const float* hn_b, const int* len, int B, int S, int H, int dh, float* out, hipStream_t s);
+               const float* hn_b, const int* len, int B, int S, int H, int dh, float* out, int out_x2, hipStream_t s);
 // xattn3.hip: the text cross-attention cores of the fp32-grade modes (bf16x3 products), head_dim 128.  qh / ql: hi / lo planes
 // [B S, D] of the query projection (after the head_dim softmax for lin_xattn3: ACT_HEADSOFTMAX; scaled by dh^-1/2 for sd_attn3)
 bool xattn3_supported(int dh, int N);
 int lin_xattn3(const uint16_t* qh, const uint16_t* ql, const float* at, int B, int S, int H, int dh, float* out, hipStream_t s);
 int sd_attn3(const uint16_t* qh, const uint16_t* ql, const float* kc, const float* vc, const int32_t* ntok, int B, int S, int H,
-             int dh, int N, float* out, hipStream_t s);
+             int dh, int N, float* out, int out_x2, hipStream_t s);
 // ntok (optional, int32 [rows / rows_per_b]): row r attends to its first ntok[r / rows_per_b] columns only, the rest get 0
 int row_softmax(float* sc, int64_t rows, int N, hipStream_t s, const int32_t* ntok = nullptr, int64_t rows_per_b = 1);
 // fused text cross-attention cores (xattn.hip), head_dim 128

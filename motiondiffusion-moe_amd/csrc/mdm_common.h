@@ -58,6 +58,18 @@ __device__ __forceinline__ void split_bf16(float a, float b, uint32_t& hi, uint3
   lo = pack_bf16(a - bf16_lo_f32(hi), b - bf16_hi_f32(hi));
 }
 
+// MDM_OP_X2_ROW rows (include/mdm_hip.h): 16-bit index of the "hi" element of column k in a row (its "lo" sits 32 elements behind);
+// four consecutive columns starting at a multiple of 4 are 8 contiguous bytes in either half
+__device__ __forceinline__ int x2_col(int k) { return ((k >> 5) << 6) + (k & 31); }
+__device__ __forceinline__ void store_x2_4(uint16_t* row, int k, float a, float b, float c, float d) {
+  uint32_t h0, h1, l0, l1;
+  split_bf16(a, b, h0, l0);
+  split_bf16(c, d, h1, l1);
+  uint16_t* p = row + x2_col(k);
+  *(uint2*)p = make_uint2(h0, h1);
+  *(uint2*)(p + 32) = make_uint2(l0, l1);
+}
+
 // ---- the 16-bit operand format of the throughput kernels -----------------------------------------------------------
 // Every single-pass MFMA kernel is templated on one of these two traits: bf16 (8 significand bits, fp32 range) or IEEE
 // fp16 (11 significand bits, |x| <= 65504).  Both MFMA forms run at the same rate on gfx950 and both conversions are

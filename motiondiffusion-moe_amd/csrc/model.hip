@@ -96,6 +96,8 @@ struct Ctx {
   int h16;          // the 16-bit format of this run: MDM_H16_BF16 (precision 1, 3) or MDM_H16_F16 (precision 2, 4)
   bool mix;         // precision 4: fp32-grade flow, but expert MLPs + the 4x FFN run as ONE fp16 pass on 16-bit operands
   bool fp8;         // precision 5: as 2, expert GEMMs on e4m3 operands (csrc/gemm8.hip)
+  bool x2;          // fp32-grade GEMM chains: a tensor whose only consumer is a bf16x3 GEMM is written PRE-SPLIT by its producer
+                    // (MDM_OP_X2_ROW rows: same bytes as fp32) -- the GEMM then does not re-split every fragment in its K loop (knob 62: off)
   int B, S, N;      // batch, frames at this scale, text tokens
   const int32_t* ntok = nullptr;  // per-sample text token counts [B] (MdmTextCache.ntok), or null: all N
   int64_t M;        // B*S
@@ -112,6 +114,9 @@ bool use_bf16_acts(const MdmModel* m, int precision) {
 // precision (include/mdm_hip.h: MDM_PREC_*) -> how this run computes; false = unsupported combination
 bool set_precision(Ctx& c, const MdmModel* m, int precision) {
   c.mix = false, c.bf = false, c.fp8 = false, c.h16 = MDM_H16_BF16;
+  // (knob 36 puts the fp32-grade Linears on the register-staged kernel, which reads fp32 rows only)
+  c.x2 = (precision == MDM_PREC_X3 || precision == MDM_PREC_MIXED) && g_bf16_variant != 62 && g_bf16_variant != 36 &&
+         (m->D == 256 || m->D == 512 || m->D == 1024) && m->F % 32 == 0;
   switch (precision) {
     case MDM_PREC_FP8:  // the fp16 throughput mode with fp8 expert GEMMs (K = D and K = F must be multiples of 128)
       c.prec = 1, c.bf = use_bf16_acts(m, MDM_PREC_F16), c.h16 = MDM_H16_F16, c.fp8 = true;
@@ -139,8 +144,10 @@ inline int fmt_mlp(const Ctx& c) { return (c.bf || c.mix) ? c.h16 : 0; }  // ...
 struct Act {
   void* p;
   bool bf;
+  bool x2 = false;  // pre-split rows (MDM_OP_X2_ROW) in an fp32-sized buffer
 };
 inline Act act_of(const Ctx& c, float* buf) { return Act{buf, c.bf}; }
+inline Act act_x2(const Ctx& c, float* buf) { return Act{buf, c.bf, !c.bf && c.x2}; }  // a tensor its producer wrote in the mode's GEMM-input form
 inline Act act_f32(const float* buf) { return Act{(void*)buf, false}; }
 inline Act act_bf16(const uint16_t* buf) { return Act{(void*)buf, true}; }
 inline Act act_h16(const void* buf) { return Act{(void*)buf, true}; }
@@ -152,6 +159,7 @@ struct LinOpts {
   const float* R2 = nullptr;
   const float* colscale = nullptr;
   int r1_mod = 0;
+  uint16_t* outx2 = nullptr;  // fp32-grade kernel: the result as pre-split rows (MdmGemmDesc.Cx2)
 };
 
 // out32 / out16 = epilogue(A @ W^T) for a plain [M,K]x[N,K] Linear; either output may be null
@@ -163,10 +171,12 @@ int linear(const Ctx& c, Act A, int64_t M, int K, const MdmPacked& W, const floa
     g.precision = 1;  // 16-bit activations: one pass of the format c.h16 (the weight was packed in it)
   } else {
     g.A = op_f32((const float*)A.p, K);
+    if (A.x2) g.A.kind = OP_X2_ROW;
   }
   g.W = packed(W);
   g.M = (int)M, g.N = N, g.K = K;
   g.C = out32, g.C16 = out16, g.ldc = N;
+  g.Cx2 = o.outx2;
   g.bias = bias;
   g.act = o.act, g.alpha = o.alpha, g.out_scale = o.out_scale;
   g.R1 = o.R1, g.ldr1 = N, g.r1_scale = o.r1_scale, g.r1_mod = o.r1_mod;
@@ -213,6 +223,7 @@ struct PerfTail {
   const float *lw = nullptr, *lb = nullptr;
   uint16_t* ln16 = nullptr;
   float* ln32 = nullptr;  // the fp32-grade modes' form of ln16 (fp32 rows; csrc/style_gemm.hip style_gemm3)
+  bool ln_x2 = false;     // ... as pre-split rows for the GEMM that reads them
   const float* skip = nullptr;
   float skip_scale = 0.f;
   const float *l2w = nullptr, *l2b = nullptr;
@@ -258,14 +269,16 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
     uint16_t* const xl = xh + c.M * 3 * D;  // the two 16-bit planes fill the fp32 [M, 3 D] buffer exactly
     GemmArgs g = gd(c);
     g.A = op_f32((const float*)xn.p, D);
+    if (xn.x2) g.A.kind = OP_X2_ROW;
     g.W = packed(p.qkv);
     g.M = (int)c.M, g.N = 3 * D, g.K = D;
     g.bias = p.qkv_b, g.alpha = 0.1f;
     g.act = ACT_HEADNORM, g.hn_w = p.hn_w, g.hn_b = p.hn_b, g.hn_l2_tiles = 2 * H;
     g.C16 = xh, g.C16_lo = xl, g.ldc = 3 * D;
     MDM_TRY(gemm(g, c.s));
-    MDM_TRY(perf_attn3(xh, xl, p.feat.hi, p.feat.lo, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, w.t4, c.s));
+    MDM_TRY(perf_attn3(xh, xl, p.feat.hi, p.feat.lo, (int)p.feat.ld, p.hn_w, p.hn_b, c.len, c.B, c.S, H, dh, w.t4, c.x2 ? 1 : 0, c.s));
   }
+  const bool t4x2 = fused3 && c.x2;  // the attention rows (t4) and the projection's hidden rows (t2) travel pre-split
   // q|k|v = 0.1 * (xn W^T + b)                                   (:145-157); bf16 when the fused attention core reads it
   if (!qkv_in && !fused3) {
     LinOpts o;
@@ -348,7 +361,12 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
       pair = true;
     }
   }
-  if (!pair) {
+  if (!pair && !c.bf && c.x2) {
+    LinOpts o;
+    o.act = ACT_GELU, o.outx2 = (uint16_t*)w.t2;
+    MDM_TRY(linear(c, Act{w.t4, false, t4x2}, c.M, D, p.proj0, p.proj0_b, D, nullptr, nullptr, o));
+    MDM_TRY(linear(c, Act{w.t2, false, true}, c.M, D, p.proj3, p.proj3_b, D, w.t4, nullptr));
+  } else if (!pair) {
     LinOpts o;
     o.act = ACT_GELU;
     MDM_TRY(linear_to_act(c, act_of(c, w.t4), c.M, D, p.proj0, p.proj0_b, D, w.t2, o));
@@ -359,6 +377,7 @@ int performer(const Ctx& c, const MdmPerformer& p, const float* x, Act xn, const
   if (!c.bf && (pt.ln32 || pt.skip)) {
     StyleTail3 t3;
     t3.lw = pt.lw, t3.lb = pt.lb, t3.ln_out = pt.ln32, t3.skip = pt.skip, t3.skip_scale = pt.skip_scale, t3.l2w = pt.l2w, t3.l2b = pt.l2b;
+    t3.ln_x2 = pt.ln_x2;
     bool did = false;
     MDM_TRY(style_apply(c, p.style, w.t4, p.post_w, p.post_b, nullptr, sc, w.t2, x, 0.1f, nullptr, out, nullptr, t16, &t3, &did));
     if (pt.done) *pt.done = did;
@@ -390,26 +409,27 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
     MDM_TRY(linear(c, tails ? act_bf16(x16) : act_f32(x), c.M, D, l.skip, l.skip_b, D, skipbuf, nullptr, o));
   }
   // h = pre_norm(x) -> t1 ; local.pre_norm(h) -> t3
-  MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, 0, l.local.pre_w, l.local.pre_b, w.t3, fmt16(c), c.s));
+  const int xnf = (!c.bf && c.x2) ? 4 : fmt16(c);  // format of the pre-normed rows the q | k | v projections read (4 = pre-split rows)
+  MDM_TRY(ln_chain(x, c.M, D, l.dual_pre_w, l.dual_pre_b, w.t1, 0, l.local.pre_w, l.local.pre_b, w.t3, xnf, c.s));
   bool normed = false;  // local_out -> t5; the fused tail also leaves global.pre_norm(local_out) in t3 (t3 is dead by then)
   {
     PerfTail pt;
     if (c.bf) pt.lw = l.global.pre_w, pt.lb = l.global.pre_b, pt.ln16 = (uint16_t*)w.t3, pt.done = &normed;
-    if (tails3) pt.lw = l.global.pre_w, pt.lb = l.global.pre_b, pt.ln32 = w.t3, pt.done = &normed;
-    MDM_TRY(performer(c, l.local, w.t1, act_of(c, w.t3), sc4 + 0 * scs, w.t5, pt));
+    if (tails3) pt.lw = l.global.pre_w, pt.lb = l.global.pre_b, pt.ln32 = w.t3, pt.ln_x2 = c.x2, pt.done = &normed;
+    MDM_TRY(performer(c, l.local, w.t1, act_x2(c, w.t3), sc4 + 0 * scs, w.t5, pt));
   }
-  if (!normed) MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
+  if (!normed) MDM_TRY(ln_chain(w.t5, c.M, D, l.global.pre_w, l.global.pre_b, w.t3, xnf, nullptr, nullptr, nullptr, 0, c.s));
   if ((tails || tails3) && normed) {
     bool done = false;
     PerfTail pt;
     pt.skip = skipbuf, pt.skip_scale = 0.1f, pt.lw = l.dual_post_w, pt.lb = l.dual_post_b, pt.done = &done;
     if (next_w && tails) pt.l2w = next_w, pt.l2b = next_b, pt.ln16 = (uint16_t*)w.t2;
-    if (next_w && tails3) pt.l2w = next_w, pt.l2b = next_b, pt.ln32 = w.t2;
-    MDM_TRY(performer(c, l.global, w.t5, act_of(c, w.t3), sc4 + 1 * scs, out, pt));
+    if (next_w && tails3) pt.l2w = next_w, pt.l2b = next_b, pt.ln32 = w.t2, pt.ln_x2 = c.x2;
+    MDM_TRY(performer(c, l.global, w.t5, act_x2(c, w.t3), sc4 + 1 * scs, out, pt));
     if (done) return MDM_OK;
     return MDM_ERR_LAUNCH;  // (unreachable: performer_tail_fused said the tail runs)
   }
-  MDM_TRY(performer(c, l.global, w.t5, act_of(c, w.t3), sc4 + 1 * scs, w.t1));  // global_out -> t1
+  MDM_TRY(performer(c, l.global, w.t5, act_x2(c, w.t3), sc4 + 1 * scs, w.t1));  // global_out -> t1
   // skip = GELU(Lin(x)); out = post_norm(skip + 0.1 * global)      (:219-225)
   {
     LinOpts o;
@@ -418,7 +438,7 @@ int dual_block(const Ctx& c, const MdmLayer& l, const float* x, const uint16_t* 
     // error for 0.01 ms per step)
     MDM_TRY(linear(c, c.bf ? act_bf16(x16) : act_f32(x), c.M, D, l.skip, l.skip_b, D, w.t3, nullptr, o));
   }
-  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, 0, next_w, next_b, next_w ? w.t2 : nullptr, fmt16(c), c.s);
+  return ln_chain(w.t3, c.M, D, l.dual_post_w, l.dual_post_b, out, 0, next_w, next_b, next_w ? w.t2 : nullptr, xnf, c.s);
 }
 
 // GatedCrossAttention (fast_attention.py:242-272): out = x + sigmoid(gate)*sigmoid(adaptive)*style(softmax(q) A)
@@ -427,7 +447,7 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
   const MdmModel& m = *c.m;
   const int D = m.D, H = m.H, dh = D / H;
   const Work& w = c.w;
-  if (!pre_normed) MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
+  if (!pre_normed) MDM_TRY(ln_chain(x, c.M, D, l.ca_norm_w, l.ca_norm_b, w.t2, (!c.bf && c.x2) ? 4 : fmt16(c), nullptr, nullptr, nullptr, 0, c.s));
   const bool fused = c.bf && lin_xattn_supported(dh) && !(dh == 256 && g_bf16_variant == 23);  // knob 23: big-width generic paths
   bool x16o = false;
   // head_dim 128: the query projection inside the attention launch (csrc/xattn.hip lin_xattn_q; knob 51: its own GEMM launch)
@@ -441,6 +461,7 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
     uint16_t* const ql = qh + c.M * D;  // the two planes fill the fp32 [M, D] buffer exactly
     GemmArgs g = gd(c);
     g.A = op_f32(w.t2, D);
+    if (c.x2) g.A.kind = OP_X2_ROW;
     g.W = packed(l.ca_q);
     g.M = (int)c.M, g.N = D, g.K = D;
     g.bias = l.ca_q_b, g.act = ACT_HEADSOFTMAX;
@@ -449,7 +470,7 @@ int cross_block(const Ctx& c, const MdmLayer& l, const float* at, const float* x
     MDM_TRY(lin_xattn3(qh, ql, at, c.B, c.S, H, dh, w.t4, c.s));
     return style_apply(c, l.ca_style, w.t4, nullptr, nullptr, nullptr, sc, w.t2, x, 1.f, l.ca_gvec, out, nullptr, false);
   }
-  if (!q_in) MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
+  if (!q_in) MDM_TRY(linear(c, act_x2(c, w.t2), c.M, D, l.ca_q, l.ca_q_b, D, fused ? nullptr : w.t3, fused ? (uint16_t*)w.t3 : nullptr));
   if (q_in) {
     x16o = g_bf16_variant != 25;
     MDM_TRY(lin_xattn_q((const uint16_t*)w.t2, l.ca_q.hi, (int)l.ca_q.ld, l.ca_q_b, at, c.B, c.S, H, dh, x16o ? nullptr : w.t4,
@@ -486,7 +507,8 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     p.gate_w[b] = l.gate_w[b], p.gate_b[b] = l.gate_b[b];
     p.usage[b] = l.usage[b], p.importance[b] = l.importance[b];
   }
-  p.hn = w.hn, p.hn_bf16 = c.fp8 ? 3 : fmt_mlp(c), p.hn_scale = w.hn_scale, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.uimp = w.uimp, p.forced_idx = forced;
+  const bool hx2 = !c.bf && !c.mix && c.x2 && D % 64 == 0;  // fp32-grade experts: LN rows and hidden rows pre-split for the two GEMMs
+  p.hn = w.hn, p.hn_bf16 = c.fp8 ? 3 : (hx2 ? 4 : fmt_mlp(c)), p.hn_scale = w.hn_scale, p.top_idx = w.top_idx, p.top_val = w.top_val, p.hist = w.hist, p.uimp = w.uimp, p.forced_idx = forced;
   MDM_TRY(moe_route(x, c.M, D, E, p, w.goff, w.cursor, w.perm, w.rowscale, w.pos4, c.s));
   if (route_out && hipMemcpyAsync(route_out, w.top_idx, 4 * c.M * sizeof(int32_t), hipMemcpyDeviceToDevice, c.s) != hipSuccess)
     return MDM_ERR_LAUNCH;
@@ -552,6 +574,7 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
       g.A.p = w.hn, g.A.ld = D, g.A.kind = OP_BF16_ROW, g.precision = 1;
     } else {
       g.A = op_f32(w.hn, D);
+      if (hx2) g.A.kind = OP_X2_ROW;
     }
     g.A.gather = w.perm;
     g.W = packed(l.w1);
@@ -560,7 +583,8 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     g.M = (int)(4 * c.M), g.N = F, g.K = D;
     g.bias = l.b1, g.bias_bs = F;
     g.act = ACT_GELU;
-    g.C = h ? nullptr : w.hid, g.C16 = h ? (uint16_t*)w.hid : nullptr, g.ldc = F;
+    g.C = (h || hx2) ? nullptr : w.hid, g.C16 = h ? (uint16_t*)w.hid : nullptr, g.ldc = F;
+    if (hx2) g.Cx2 = (uint16_t*)w.hid;
     MDM_TRY(gemm(g, c.s));
   }
   {
@@ -569,6 +593,7 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
       g.A.p = w.hid, g.A.ld = F, g.A.kind = OP_BF16_ROW, g.precision = 1;
     } else {
       g.A = op_f32(w.hid, F);
+      if (hx2) g.A.kind = OP_X2_ROW;
     }
     g.W = packed(l.w2);
     g.W.bs1 = (int64_t)D * l.w2.ld;
@@ -646,7 +671,7 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
     g.bias = l.sd_q_b, g.alpha = 1.f / sqrtf((float)dh);
     g.C16 = qh, g.C16_lo = ql, g.ldc = D;
     MDM_TRY(gemm(g, c.s));
-    MDM_TRY(sd_attn3(qh, ql, kc, vc, c.ntok, c.B, c.S, H, dh, N, w.t2, c.s));
+    MDM_TRY(sd_attn3(qh, ql, kc, vc, c.ntok, c.B, c.S, H, dh, N, w.t2, c.x2 ? 1 : 0, c.s));
   } else {
     LinOpts o;
     o.alpha = 1.f / sqrtf((float)dh);
@@ -683,18 +708,20 @@ int sdcross_block(const Ctx& c, const MdmLayer& l, const float* kc, const float*
       MDM_TRY(gemm(g, c.s));
     }
   }
-  MDM_TRY(linear(c, act_of(c, w.t2), c.M, D, l.sd_out, l.sd_out_b, D, w.t3, nullptr));
-  // the 4x FFN (LayerNorm -> Linear -> GELU -> Linear): 16-bit operands in the throughput AND the mixed mode
-  const bool h = c.bf || c.mix;
-  MDM_TRY(ln_chain(w.t3, c.M, D, l.sd_ln_w, l.sd_ln_b, w.t4, fmt_mlp(c), nullptr, nullptr, nullptr, 0, c.s));
+  MDM_TRY(linear(c, Act{w.t2, c.bf, fused3 && c.x2}, c.M, D, l.sd_out, l.sd_out_b, D, w.t3, nullptr));
+  // the 4x FFN (LayerNorm -> Linear -> GELU -> Linear): 16-bit operands in the throughput AND the mixed mode; in the fp32-grade
+  // mode the LayerNorm rows and the hidden rows are written pre-split for the GEMM that reads them
+  const bool h = c.bf || c.mix, fx2 = !h && c.x2;
+  MDM_TRY(ln_chain(w.t3, c.M, D, l.sd_ln_w, l.sd_ln_b, w.t4, fx2 ? 4 : fmt_mlp(c), nullptr, nullptr, nullptr, 0, c.s));
   {
     LinOpts o;
     o.act = ACT_GELU;
-    MDM_TRY(linear(c, Act{w.t4, h}, c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, h ? nullptr : w.f1, h ? (uint16_t*)w.f1 : nullptr, o));
+    if (fx2) o.outx2 = (uint16_t*)w.f1;
+    MDM_TRY(linear(c, Act{w.t4, h, fx2}, c.M, D, l.sd_f1, l.sd_f1_b, 4 * D, (h || fx2) ? nullptr : w.f1, h ? (uint16_t*)w.f1 : nullptr, o));
   }
   LinOpts o;  // x + (o + ffn(o))
   o.R1 = x, o.R2 = w.t3;
-  return linear(c, Act{w.f1, h}, c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, out16, o);
+  return linear(c, Act{w.f1, h, fx2}, c.M, 4 * D, l.sd_f2, l.sd_f2_b, D, out, out16, o);
 }
 
 const float* tc_at(const MdmModel& m, const MdmTextCache& tc, int layer) {

@@ -94,7 +94,8 @@ struct Attn3Args {
   const float* hn_b;
   const int* len;
   int S, H;
-  float* out;          // fp32 [B S, D]
+  float* out;          // fp32 [B S, D], or (out_x2) the same rows pre-split: MDM_OP_X2_ROW, 2 D 16-bit elements per row
+  int out_x2;
 };
 
 __global__ __launch_bounds__(A3_NT) void perf_attn3_kernel(const Attn3Args g) {
@@ -309,12 +310,17 @@ __global__ __launch_bounds__(A3_NT) void perf_attn3_kernel(const Attn3Args g) {
     const float rstd = rsqrtf(quad_sum3(s2) * (1.f / A3_DH) + 1e-5f);
     if (t < S) {
       float* orow = g.out + (rowbase + t) * D + h * A3_DH;
+      uint16_t* xrow = (uint16_t*)g.out + (rowbase + t) * 2 * D;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         const f32x4 w = *(const f32x4*)(g.hn_w + 16 * dt + 4 * q), bb = *(const f32x4*)(g.hn_b + 16 * dt + 4 * q);
         const f32x4 y = {an[dt][0] * rstd * w[0] + bb[0], an[dt][1] * rstd * w[1] + bb[1], an[dt][2] * rstd * w[2] + bb[2],
                          an[dt][3] * rstd * w[3] + bb[3]};
-        *(f32x4*)(orow + 16 * dt + 4 * q) = y;
+        if (g.out_x2) {
+          store_x2_4(xrow, h * A3_DH + 16 * dt + 4 * q, y[0], y[1], y[2], y[3]);
+        } else {
+          *(f32x4*)(orow + 16 * dt + 4 * q) = y;
+        }
       }
     }
   }
@@ -326,7 +332,7 @@ bool perf_attn3_supported(int dh, int S) { return dh == A3_DH && S >= 1 && S <= 
 
 // xh / xl: hi / lo planes of the normalised q | k | v rows [B S, 3 D] (D = H * 128); ph / pl: P^T planes [128][ldp]; out fp32 [B S, D]
 int perf_attn3(const uint16_t* xh, const uint16_t* xl, const uint16_t* ph, const uint16_t* pl, int ldp, const float* hn_w,
-               const float* hn_b, const int* len, int B, int S, int H, int dh, float* out, hipStream_t s) {
+               const float* hn_b, const int* len, int B, int S, int H, int dh, float* out, int out_x2, hipStream_t s) {
   if (!perf_attn3_supported(dh, S)) return MDM_ERR_UNSUPPORTED;
   if (!xh || !xl || !ph || !pl || !hn_w || !hn_b || !len || !out || B <= 0 || H <= 0 || (ldp & 7) ||
       ((((uintptr_t)xh) | ((uintptr_t)xl) | ((uintptr_t)ph) | ((uintptr_t)pl) | ((uintptr_t)hn_w) | ((uintptr_t)hn_b) | ((uintptr_t)out)) & 15))
@@ -337,7 +343,7 @@ int perf_attn3(const uint16_t* xh, const uint16_t* xl, const uint16_t* ph, const
       return MDM_ERR_LAUNCH;
     attr = true;
   }
-  const Attn3Args g = {xh, xl, ph, pl, ldp, hn_w, hn_b, len, S, H, out};
+  const Attn3Args g = {xh, xl, ph, pl, ldp, hn_w, hn_b, len, S, H, out, out_x2};
   hipLaunchKernelGGL(perf_attn3_kernel, dim3(B * H), dim3(A3_NT), A3_SMEM, s, g);
   MDM_RETURN_IF_LAUNCH_FAILED();
   return MDM_OK;

@@ -95,6 +95,23 @@ struct Row {
       store_h16<1>(p, D, lane);
     }
   }
+  // MDM_OP_X2_ROW row (include/mdm_hip.h): bf16 hi / lo halves per block of 32 columns, the pre-split operand of the fp32-grade GEMM
+  __device__ __forceinline__ void store_x2(uint16_t* __restrict__ p, int D, int lane) const {
+    static_assert(VEC, "x2 rows exist for the vector widths only");
+#pragma unroll
+    for (int c = 0; c < NE / 4; ++c) store_x2_4(p, 4 * (lane + 64 * c), e[4 * c + 0], e[4 * c + 1], e[4 * c + 2], e[4 * c + 3]);
+  }
+  // mode 0 fp32, 1 the launch's 16-bit format, 2 x2 rows (2 D 16-bit elements per row)
+  template <int FMT>
+  __device__ __forceinline__ void store_mode(void* __restrict__ p, int64_t row, int D, int lane, int mode) const {
+    if constexpr (VEC) {
+      if (mode == 2) {
+        store_x2((uint16_t*)p + row * 2 * D, D, lane);
+        return;
+      }
+    }
+    store_to<FMT>(p, row, D, lane, mode == 1);
+  }
   // fp32 or 16-bit destination, format fixed at compile time
   template <int FMT>
   __device__ __forceinline__ void store_to(void* __restrict__ p, int64_t row, int D, int lane, bool h16) const {

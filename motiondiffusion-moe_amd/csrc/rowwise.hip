@@ -13,8 +13,8 @@ namespace {
 // that the conversions are straight-line code and every load of an iteration is issued before the first wait (row.h)
 template <int NE, bool VEC, int FMT>
 __device__ __forceinline__ void ln_chain_rows(const float* __restrict__ x, bool x_h, int64_t M, int D, const float* w1,
-                                              const float* b1, void* y1, bool y1_h, const float* w2, const float* b2,
-                                              void* y2, bool y2_h) {
+                                              const float* b1, void* y1, int y1_h, const float* w2, const float* b2,
+                                              void* y2, int y2_h) {  // y?_h: 0 fp32, 1 16-bit (FMT), 2 x2 rows
   const int lane = threadIdx.x & 63;
   Row<NE, VEC> ww1, bb1, ww2, bb2;
   ww1.load(w1, D, lane), bb1.load(b1, D, lane);
@@ -33,14 +33,14 @@ __device__ __forceinline__ void ln_chain_rows(const float* __restrict__ x, bool 
     r.layernorm(ww1, bb1, D, lane);
     q.layernorm(ww1, bb1, D, lane);
     if (y1) {
-      r.template store_to<FMT>(y1, row, D, lane, y1_h);
-      if (two) q.template store_to<FMT>(y1, row + 1, D, lane, y1_h);
+      r.template store_mode<FMT>(y1, row, D, lane, y1_h);
+      if (two) q.template store_mode<FMT>(y1, row + 1, D, lane, y1_h);
     }
     if (w2) {
       r.layernorm(ww2, bb2, D, lane);
       q.layernorm(ww2, bb2, D, lane);
-      r.template store_to<FMT>(y2, row, D, lane, y2_h);
-      if (two) q.template store_to<FMT>(y2, row + 1, D, lane, y2_h);
+      r.template store_mode<FMT>(y2, row, D, lane, y2_h);
+      if (two) q.template store_mode<FMT>(y2, row + 1, D, lane, y2_h);
     }
   }
 }
@@ -48,10 +48,11 @@ template <int NE, bool VEC>
 __global__ __launch_bounds__(256) void ln_chain_kernel(const float* __restrict__ x, int x_bf, int64_t M, int D,
                                                        const float* w1, const float* b1, void* y1, int y1_bf,
                                                        const float* w2, const float* b2, void* y2, int y2_bf) {
-  if ((x_bf | y1_bf | y2_bf) == 2) {
-    ln_chain_rows<NE, VEC, 2>(x, x_bf != 0, M, D, w1, b1, y1, y1_bf != 0, w2, b2, y2, y2_bf != 0);
+  const int m1 = y1_bf == 4 ? 2 : (y1_bf != 0), m2 = y2_bf == 4 ? 2 : (y2_bf != 0);  // 4 = x2 rows (MDM_OP_X2_ROW)
+  if (((x_bf | y1_bf | y2_bf) & 3) == 2) {
+    ln_chain_rows<NE, VEC, 2>(x, x_bf != 0, M, D, w1, b1, y1, m1, w2, b2, y2, m2);
   } else {
-    ln_chain_rows<NE, VEC, 1>(x, x_bf != 0, M, D, w1, b1, y1, y1_bf != 0, w2, b2, y2, y2_bf != 0);
+    ln_chain_rows<NE, VEC, 1>(x, x_bf != 0, M, D, w1, b1, y1, m1, w2, b2, y2, m2);
   }
 }
 
@@ -324,9 +325,13 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
             *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + rc) * D + k) = make_uint2(pack_h16(HNF, h[0], h[1]), pack_h16(HNF, h[2], h[3]));
           } else if constexpr (HNF == 0) {
             *(f32x4*)((float*)p.hn + ((int64_t)br * M + rc) * D + k) = h;
+          } else if constexpr (HNF == 4) {  // x2 rows (MDM_OP_X2_ROW): what the fp32-grade expert GEMM reads without re-splitting
+            store_x2_4((uint16_t*)p.hn + ((int64_t)br * M + rc) * 2 * D, k, h[0], h[1], h[2], h[3]);
           }
         } else if (ok && p.hn_bf16 != 3) {
-          if (p.hn_bf16 == 2) {  // (one uniform branch per chunk, not one per converted pair)
+          if (p.hn_bf16 == 4) {
+            store_x2_4((uint16_t*)p.hn + ((int64_t)br * M + row) * 2 * D, k, h[0], h[1], h[2], h[3]);
+          } else if (p.hn_bf16 == 2) {  // (one uniform branch per chunk, not one per converted pair)
             *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_h16(2, h[0], h[1]), pack_h16(2, h[2], h[3]));
           } else if (p.hn_bf16) {
             *(uint2*)((uint16_t*)p.hn + ((int64_t)br * M + row) * D + k) = make_uint2(pack_h16(1, h[0], h[1]), pack_h16(1, h[2], h[3]));
@@ -795,7 +800,10 @@ int ln_chain(const float* x, int64_t M, int D, const float* w1, const float* b1,
              const float* b2, void* y2, int y2_bf, hipStream_t s, int x_bf) {
   if (M <= 0) return MDM_OK;
   if (!x || !w1 || !b1 || (w2 && (!b2 || !y2)) || (!w2 && !y1)) return MDM_ERR_ARG;
-  if ((unsigned)x_bf > 2 || (unsigned)y1_bf > 2 || (unsigned)y2_bf > 2 || (x_bf | y1_bf | y2_bf) == 3) return MDM_ERR_ARG;  // one 16-bit format per launch
+  // formats: 0 fp32, 1 / 2 the launch's ONE 16-bit format, 4 (outputs only) x2 rows: D a multiple of 256 (the vector row widths)
+  if ((unsigned)x_bf > 2 || (y1_bf != 4 && (unsigned)y1_bf > 2) || (y2_bf != 4 && (unsigned)y2_bf > 2) || ((x_bf | y1_bf | y2_bf) & 3) == 3)
+    return MDM_ERR_ARG;
+  if ((y1_bf == 4 || y2_bf == 4) && D != 256 && D != 512 && D != 1024) return MDM_ERR_UNSUPPORTED;
 #define CALL(NE, VEC) \
   hipLaunchKernelGGL((ln_chain_kernel<NE, VEC>), dim3(row_grid((M + 1) / 2)), dim3(256), 0, s, x, x_bf, M, D, w1, b1, y1, y1_bf, w2, b2, y2, y2_bf)
   MDM_ROW_DISPATCH(D, CALL);
@@ -848,6 +856,9 @@ bool gate16_const_fmt(int grid, int smem, hipStream_t s, const float* x, int64_t
     case 0:
       if constexpr (NV == 8 && EX == 8) return launch_gate16_const<NV, EX, 0, false>(grid, smem, s, x, M, D, E, p);
       return false;
+    case 4:  // the same rows pre-split (x2): same logits, same routing
+      if constexpr (NV == 8 && EX == 8) return launch_gate16_const<NV, EX, 4, false>(grid, smem, s, x, M, D, E, p);
+      return false;
     default: return false;  // fp8 rows are written after the logit loop: nothing per chunk pins the FMAs, and they sink again
   }
 }
@@ -880,7 +891,7 @@ int moe_route(const float* x, int64_t M, int D, int E, const MoeGateParams& p, i
 #define GATE16(NV)                                                                                            \
   do {                                                                                                        \
     if (gate16_const_wanted(NV, E) && gate16_const(NV, grid, smem, s, x, M, D, E, p)) {                      \
-    } else if (p.hn_bf16) {                                                                                   \
+    } else if (p.hn_bf16 && p.hn_bf16 != 4) {                                                                 \
       hipLaunchKernelGGL((moe_gate16_kernel<NV, true>), dim3(grid), dim3(256), smem, s, x, M, D, E, p);       \
     } else {                                                                                                  \
       hipLaunchKernelGGL((moe_gate16_kernel<NV, false>), dim3(grid), dim3(256), smem, s, x, M, D, E, p);      \

@@ -55,6 +55,7 @@ struct StyleGemmArgs {
   const float* skip;
   float skip_scale;
   const float *l2w, *l2b;
+  int ln_x2;  // ln_out as pre-split rows (MDM_OP_X2_ROW) for the GEMM that reads it, instead of fp32
 };
 
 template <typename HT, bool SRC16, int SG_RT>
@@ -376,13 +377,15 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm3_kerne
         r.store(g.out + m * D, D, lane);
         if (g.l2w) {
           r.layernorm(l2ww, l2bb, D, lane);
-          r.store(g.ln_out + m * D, D, lane);
+          if (g.ln_x2) r.store_x2((uint16_t*)g.ln_out + m * 2 * D, D, lane);
+          else r.store(g.ln_out + m * D, D, lane);
         }
       } else {
         r.store(g.out + m * D, D, lane);
         if (g.lw) {
           r.layernorm(lww, lbb, D, lane);
-          r.store(g.ln_out + m * D, D, lane);
+          if (g.ln_x2) r.store_x2((uint16_t*)g.ln_out + m * 2 * D, D, lane);
+          else r.store(g.ln_out + m * D, D, lane);
         }
       }
     }
@@ -516,7 +519,7 @@ int style_gemm3(const float* src, int64_t M, int D, int S, const float* pw, cons
   StyleGemmArgs g = {};
   g.src = src, g.M = M, g.S = S, g.pw = pw, g.pb = pb, g.sw = sw, g.sb = sb, g.sc = sc, g.pos4 = pos4, g.ws = ws3, g.bias = bias;
   g.resid = resid, g.out_scale = out_scale, g.colscale = colscale, g.out = out;
-  g.lw = t.lw, g.lb = t.lb, g.ln_out = t.ln_out, g.skip = t.skip, g.skip_scale = t.skip_scale, g.l2w = t.l2w, g.l2b = t.l2b;
+  g.lw = t.lw, g.lb = t.lb, g.ln_out = t.ln_out, g.skip = t.skip, g.skip_scale = t.skip_scale, g.l2w = t.l2w, g.l2b = t.l2b, g.ln_x2 = t.ln_x2;
   if (g_bf16_variant == 58) return launch_style_gemm3<4>(g, s);  // A/B knob: 64-row tiles
   return launch_style_gemm3<2>(g, s);
 }

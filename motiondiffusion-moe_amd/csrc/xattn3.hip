@@ -126,7 +126,8 @@ struct SdX3Args {
   const float* vc;     // values [B, N, D]
   const int32_t* ntok; // optional per-sample token counts
   int N, S, H;
-  float* out;          // fp32 [B S, D]
+  float* out;          // fp32 [B S, D], or (out_x2) the same rows pre-split (MDM_OP_X2_ROW) for the output projection
+  int out_x2;
 };
 
 template <int NS>  // k steps of 32 keys: ceil(N / 32), compiled in (with a run-time bound hipcc spills the score accumulators)
@@ -228,8 +229,15 @@ __global__ __launch_bounds__(X3_NT) void sd_attn3_kernel(const SdX3Args g) {
       }
     if (t < S) {
       float* orow = g.out + (rowbase + t) * D + h * X3_DH;
+      uint16_t* xrow = (uint16_t*)g.out + (rowbase + t) * 2 * D;
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) *(f32x4*)(orow + 16 * dt + 4 * q) = o[dt];
+      for (int dt = 0; dt < 8; ++dt) {
+        if (g.out_x2) {
+          store_x2_4(xrow, h * X3_DH + 16 * dt + 4 * q, o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+        } else {
+          *(f32x4*)(orow + 16 * dt + 4 * q) = o[dt];
+        }
+      }
     }
   }
 }
@@ -256,7 +264,7 @@ int lin_xattn3(const uint16_t* qh, const uint16_t* ql, const float* at, int B, i
 }
 
 int sd_attn3(const uint16_t* qh, const uint16_t* ql, const float* kc, const float* vc, const int32_t* ntok, int B, int S, int H,
-             int dh, int N, float* out, hipStream_t s) {
+             int dh, int N, float* out, int out_x2, hipStream_t s) {
   if (!xattn3_supported(dh, N)) return MDM_ERR_UNSUPPORTED;
   if (!qh || !ql || !kc || !vc || !out || B <= 0 || S <= 0 || H <= 0 ||
       ((((uintptr_t)qh) | ((uintptr_t)ql) | ((uintptr_t)kc) | ((uintptr_t)vc) | ((uintptr_t)out)) & 15))
@@ -271,7 +279,7 @@ int sd_attn3(const uint16_t* qh, const uint16_t* ql, const float* kc, const floa
       return MDM_ERR_LAUNCH;
     attr = true;
   }
-  const SdX3Args g = {qh, ql, kc, vc, ntok, N, S, H, out};
+  const SdX3Args g = {qh, ql, kc, vc, ntok, N, S, H, out, out_x2};
   switch ((N + 31) >> 5) {
     case 1: hipLaunchKernelGGL(sd_attn3_kernel<1>, dim3(B * H), dim3(X3_NT), smem, s, g); break;
     case 2: hipLaunchKernelGGL(sd_attn3_kernel<2>, dim3(B * H), dim3(X3_NT), smem, s, g); break;

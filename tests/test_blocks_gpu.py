@@ -388,3 +388,23 @@ def test_fp32_grade_stylization_in_one_launch(B, S, precision):
               f"fused vs two {e_two:.2e}, vs fused-without-tails {e_ln:.2e}")
         assert torch.isfinite(out).all()
         assert e_ref < 1e-3 and e_two < 2e-4 and e_ln < 2e-4
+
+
+@pytest.mark.parametrize("precision", [3, 4])
+@pytest.mark.parametrize("B,S,N", [(2, 98, 28), (3, 196, 6), (1, 5, 85)])
+def test_pre_split_rows_between_fp32_grade_gemms_change_nothing(B, S, N, precision):
+    """MDM_OP_X2_ROW: in the fp32-grade modes a tensor whose only consumer is a bf16x3 GEMM is written pre-split (bf16 hi | lo per
+    block of 32 columns) by its producer -- LayerNorm kernels, attention cores, the router's LN rows, GEMM epilogues -- so that the
+    GEMM does not re-split every fp32 fragment in its K loop.  The split is the same function of the same fp32 value wherever it
+    happens, so every block's output must be bit-identical with the plumbing switched off (knob 62)."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, N, precision)
+    L = pkg("_lib")
+    for block in (L.BLOCK_DUAL, L.BLOCK_CROSS, L.BLOCK_MOE, L.BLOCK_SDCROSS, L.BLOCK_LAYER):
+        out = _run_block(m, block, h, sc, length, xf)
+        L.lib().mdm_set_gemm_variant(62)
+        try:
+            plain = _run_block(m, block, h, sc, length, xf)
+        finally:
+            L.lib().mdm_set_gemm_variant(0)
+        assert torch.isfinite(out).all()
+        assert torch.equal(out, plain), (block, float((out - plain).abs().max()))

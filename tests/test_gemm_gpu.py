@@ -395,3 +395,47 @@ def test_plane_outputs_and_head_softmax_epilogue(M):
         err = float(((hi.double() + lo.double()) - ref).abs().max() / ref.abs().max())
         print(f"M={M} act={act}: planes vs fp64 {err:.2e}")
         assert err < 3e-5
+
+
+@pytest.mark.parametrize("M,N,K,grouped", [(12544, 512, 512, False), (300, 1024, 512, False), (515, 512, 1024, True)])
+def test_x3_gemm_on_pre_split_rows_is_bit_identical(M, N, K, grouped):
+    """MDM_OP_X2_ROW activations (csrc/gemm3.hip AX2): a first GEMM writes its result pre-split (MdmGemmDesc.Cx2) beside the fp32
+    copy, a second GEMM reads either form (dense, and grouped with a row gather): bit-identical results, and Cx2 holds exactly
+    split_bf16 of the fp32 copy in the documented layout."""
+    L, ops = _mods()
+    x = _rand(M, 256, seed=1)
+    w0 = _rand(K, 256, seed=2) * 256 ** -0.5
+    G = 3 if grouped else 1
+    w1 = _rand(G, N, K, seed=3) * K ** -0.5
+    pw0, pw1 = ops.PackedWeight(w0), ops.PackedWeight(w1 if grouped else w1[0])
+    mid = torch.zeros(M, K, device="cuda")
+    midx2 = torch.zeros(M, 2 * K, dtype=torch.bfloat16, device="cuda")
+    d = ops.gemm_desc(3)
+    d.A = ops.f32_operand(x, 256)
+    d.W = pw0.operand()
+    d.M, d.N, d.K = M, K, 256
+    d.C, d.Cx2, d.ldc, d.act = mid.data_ptr(), midx2.data_ptr(), K, L.ACT_GELU
+    ops.run_gemm(d)
+    hi = mid.to(torch.bfloat16)
+    lo = (mid - hi.float()).to(torch.bfloat16)
+    want = torch.stack([hi.reshape(M, K // 32, 32), lo.reshape(M, K // 32, 32)], 2).reshape(M, 2 * K)
+    assert torch.equal(midx2.view(torch.int16), want.view(torch.int16))
+    sizes = [200, 0, 315] if grouped else [M]
+    goff = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    gather = torch.randint(0, M, (M,), generator=g, dtype=torch.int32).cuda() if grouped else None
+    outs = []
+    for kind, buf in ((L.OP_F32_ROW, mid), (L.OP_X2_ROW, midx2)):
+        e = ops.gemm_desc(3)
+        e.A = ops.f32_operand(buf, K)  # ld in 4-byte units in both forms
+        e.A.kind = kind
+        e.A.gather = L.ptr(gather)
+        e.W = pw1.operand()
+        e.M, e.N, e.K = sum(sizes), N, K
+        out = torch.zeros(M, N, device="cuda")
+        e.C, e.ldc = out.data_ptr(), N
+        if grouped:
+            e.goff, e.ngroups, e.W.bs1 = goff.data_ptr(), G, N * pw1.Kp
+        ops.run_gemm(e)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
