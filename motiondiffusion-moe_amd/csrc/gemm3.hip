@@ -297,7 +297,7 @@ __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
             v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
           }
           if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;
-          if (g.Cx2) store_x2_4(g.Cx2 + (int64_t)m * 2 * g.ldc, n, v[0], v[1], v[2], v[3]);  // pre-split rows for the next GEMM
+          if (g.Cx2) store_x2_4p(g.Cx2 + (int64_t)m * 2 * g.ldc, n, v[0], v[1], v[2], v[3]);  // pre-split rows for the next GEMM (lane pairs: N % 32 == 0)
           if (g.C16_lo) {  // bf16 hi / lo planes (the operand format of the fp32-grade attention cores)
             uint32_t h0, h1, l0, l1;
             split_bf16(v[0], v[1], h0, l0);

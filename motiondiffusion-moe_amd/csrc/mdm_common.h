@@ -70,6 +70,21 @@ __device__ __forceinline__ void store_x2_4(uint16_t* row, int k, float a, float 
   *(uint2*)(p + 32) = make_uint2(l0, l1);
 }
 
+// The same when the lanes l and l ^ 1 hold the column groups k and k ^ 4 of ONE row (row kernels, GEMM epilogues): the pair trades
+// halves through a quad-permute (a VALU move) so that the even lane stores the 8 hi values and the odd lane the 8 lo values of their
+// 8 columns as ONE 16-byte store each (two 8-byte stores per lane move the same bytes in twice the store instructions).
+__device__ __forceinline__ void store_x2_4p(uint16_t* row, int k, float a, float b, float c, float d) {
+  uint32_t h0, h1, l0, l1;
+  split_bf16(a, b, h0, l0);
+  split_bf16(c, d, h1, l1);
+  const bool odd = (k >> 2) & 1;
+  const uint32_t s0 = odd ? h0 : l0, s1 = odd ? h1 : l1;  // what the partner needs: the even lane's lo, the odd lane's hi
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+  const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xf, 0xf, false);
+  uint16_t* p = row + x2_col(k & ~7) + (odd ? 32 : 0);
+  *(uint4*)p = odd ? make_uint4(r0, r1, l0, l1) : make_uint4(h0, h1, r0, r1);
+}
+
 // ---- the 16-bit operand format of the throughput kernels -----------------------------------------------------------
 // Every single-pass MFMA kernel is templated on one of these two traits: bf16 (8 significand bits, fp32 range) or IEEE
 // fp16 (11 significand bits, |x| <= 65504).  Both MFMA forms run at the same rate on gfx950 and both conversions are

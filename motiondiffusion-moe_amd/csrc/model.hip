@@ -757,6 +757,7 @@ int decoder_layer(const Ctx& c, int layer, const MdmTextCache& tc, float* x, uin
                ? MDM_OK
                : MDM_ERR_LAUNCH;
   };
+  if (!c.bf) x16 = y16 = nullptr;  // the 16-bit shadows of the residual stream are read by the 16-bit modes only: do not write them here
   MDM_TRY(dual_block(c, l, x, x16, sc4, y, l.ca_norm_w, l.ca_norm_b));
   MDM_TRY(dump(0, y));
   MDM_TRY(cross_block(c, l, tc_at(m, tc, layer), y, sc4 + 2 * scs, x, true));

@@ -99,7 +99,7 @@ struct Row {
   __device__ __forceinline__ void store_x2(uint16_t* __restrict__ p, int D, int lane) const {
     static_assert(VEC, "x2 rows exist for the vector widths only");
 #pragma unroll
-    for (int c = 0; c < NE / 4; ++c) store_x2_4(p, 4 * (lane + 64 * c), e[4 * c + 0], e[4 * c + 1], e[4 * c + 2], e[4 * c + 3]);
+    for (int c = 0; c < NE / 4; ++c) store_x2_4p(p, 4 * (lane + 64 * c), e[4 * c + 0], e[4 * c + 1], e[4 * c + 2], e[4 * c + 3]);
   }
   // mode 0 fp32, 1 the launch's 16-bit format, 2 x2 rows (2 D 16-bit elements per row)
   template <int FMT>

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void moe_gate16_kernel(const float* __restrict
           } else if constexpr (HNF == 0) {
             *(f32x4*)((float*)p.hn + ((int64_t)br * M + rc) * D + k) = h;
           } else if constexpr (HNF == 4) {  // x2 rows (MDM_OP_X2_ROW): what the fp32-grade expert GEMM reads without re-splitting
-            store_x2_4((uint16_t*)p.hn + ((int64_t)br * M + rc) * 2 * D, k, h[0], h[1], h[2], h[3]);
+            store_x2_4p((uint16_t*)p.hn + ((int64_t)br * M + rc) * 2 * D, k, h[0], h[1], h[2], h[3]);
           }
         } else if (ok && p.hn_bf16 != 3) {
           if (p.hn_bf16 == 4) {

@@ -13,6 +13,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# a GPU box shows every host core to a process that is given a share of them: torch's default thread count then oversubscribes, and
+# the small CPU ops the oracle and the seeded weight builders are made of run several times slower
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
@@ -36,8 +40,20 @@ def rel_inf(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
 
 
+_STATE_MEMO = {}
+
+
 def golden_state(meta):
-    """Rebuild (state_dict, eph dict, proj dict, model cfg) for a golden case from its seeds."""
+    """Rebuild (state_dict, eph dict, proj dict, model cfg) for a golden case from its seeds (memoised per case: the tensors are
+    shared between tests and treated as read-only; the dicts are fresh, so a test may rebind keys)."""
+    key = json.dumps({"cfg": meta["cfg"], "wseed": meta["wseed"], "D": meta["latent_dim"], "Dt": meta["text_latent_dim"]}, sort_keys=True)
+    if key not in _STATE_MEMO:
+        _STATE_MEMO[key] = _golden_state(meta)
+    sd, eph, proj, mcfg = _STATE_MEMO[key]
+    return dict(sd), dict(eph), dict(proj), dict(mcfg)
+
+
+def _golden_state(meta):
     synth = pkg("synth")
     model = pkg("layout")
     cfg = meta["cfg"]
