@@ -609,13 +609,16 @@ def main():
                 pk = next((v for k, v in per if str(k).startswith("fused_mlp_stream_kernel") and ", 7, 4, 512, 0>" in str(k)), None)
                 pmc_k = (pk["fetch_x2"] + pk["write"]) * 1e6 if pk else None
             rf = line["roofline"]
+            x3 = a.precision == 3  # the fp32-grade mode runs the expert MLP as two grouped bf16x3 GEMMs; the probe brackets the pair
+            kname = ("gemm_x3_kernel<128, 128, 2, GELU | none> x 2 (the expert MLP as its two grouped bf16x3 GEMMs, csrc/gemm3.hip)" if x3
+                     else "fused_mlp_stream_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip)")
             rf.update({"achieved": round(live[1] / live[0] / 1e12, 2), "frac": round(live[1] / live[0] / PEAK[a.precision], 4),
-                       "traffic": pmc_k,
-                       "traffic_note": ("per launch of this kernel (mean over its launches in a step); " + traffic_note) if pmc_k else traffic_note,
-                       "what": "dominant kernel fused_mlp_stream_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip): mean algorithmic FLOP per "
+                       "traffic": None if x3 else pmc_k,
+                       "traffic_note": ("per launch of this kernel (mean over its launches in a step); " + traffic_note) if (pmc_k and not x3) else traffic_note,
+                       "what": f"dominant kernel {kname}: mean algorithmic FLOP per "
                                "launch (4 * routed rows * D * F) / mean launch duration over the launches of real sampling "
                                "steps; the whole step is under whole_step",
-                       "kernel": "fused_mlp_stream_kernel", "launch_us_mean": round(live[0] * 1e6, 1),
+                       "kernel": kname.split(" (")[0], "launch_us_mean": round(live[0] * 1e6, 1),
                        "flop_per_launch_mean": live[1], "launches_timed": len(live[2]),
                        "launches": [{"rows": rw, "us": round(u, 1)} for rw, u in live[2][:8]],
                        "timed_with": "HIP events recorded by the library on the launch stream around every launch of the "
