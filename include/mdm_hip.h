@@ -110,6 +110,10 @@ typedef struct MdmGemmDesc {
   int32_t hn_l2_tiles;
   /* fp32-grade kernel: the result as MDM_OP_X2_ROW rows (row stride 2 * ldc 16-bit elements; N % 32 == 0), beside or instead of C */
   uint16_t* Cx2;
+  /* optional fragment stream of W (mdm_gemm_stream1_pack, format h16): a plain Linear on 16-bit rows (precision 1 / 2, no batch /
+   * groups / gather, act NONE or GELU, N % 256 == K % 256 == 0) then runs on the streamed-weight kernel (csrc/gemm_stream.hip);
+   * anything else ignores it */
+  const uint16_t* w_stream;
 } MdmGemmDesc;
 
 int mdm_gemm(const MdmGemmDesc* desc, void* stream);
@@ -164,6 +168,12 @@ int mdm_mlp_stream_pack(const float* w1, const float* w2, int32_t G, int32_t F, 
  * the buffer needs (0 = shape not taken) and the packer. */
 int64_t mdm_gemm_stream_elems(int32_t N, int32_t K);
 int mdm_gemm_stream_pack(const float* w, int32_t N, int32_t K, int32_t h16, uint16_t* out, void* stream);
+/* Fragment stream of a [N, K] fp32 weight for the streamed-weight GEMM (MdmGemmDesc.w_stream / MdmPacked.ws): [N / 16][K / 32]
+ * MFMA operand fragments of 1 KiB in the 16-bit format h16, plus the read-ahead pad.  elems: 16-bit elements to allocate, 0 when the
+ * shape is not covered (N % 256, K % 256). */
+int64_t mdm_gemm_stream1_elems(int32_t N, int32_t K);
+int mdm_gemm_stream1_pack(const float* w, int64_t ldw, int32_t N, int32_t K, int32_t h16, uint16_t* out, void* stream);
+
 /* the same for the fp32-grade (bf16x3) form of that kernel: (bf16 hi, lo = rn(w - hi)) fragment PAIRS in consumption order,
  * 2 * N * K + 16 KiB of tail padding elements (0 = shape not taken) */
 int64_t mdm_gemm_stream3_elems(int32_t N, int32_t K);
@@ -184,6 +194,7 @@ typedef struct MdmPacked { /* 16-bit planes of an fp32 [N,K] weight, K padded to
   const uint16_t* hi; /* bf16 hi plane, or the fp16 plane of a weight packed for a single fp16 pass */
   const uint16_t* lo; /* bf16 lo plane (bf16x3); for an fp8-packed weight (hi = e4m3 bytes): its per-row fp32 scales; else NULL */
   int64_t ld;
+  const uint16_t* ws; /* optional fragment stream of the same weight in the model's 16-bit format (mdm_gemm_stream1_pack), or NULL */
 } MdmPacked;
 
 typedef struct MdmStyle { /* StylizationBlock minus its emb_layers (those are stacked model-wide), stylization.py:5-31 */
@@ -437,7 +448,11 @@ int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
  * the query of the linear cross-attention; 22 unfolded text cross-attention, 24 folded at any pass count;
  * 23 generic head_dim-256 paths; 25 fp32 instead of 16-bit intermediates; 26 / 27 router with compile-time / run-time expert
  * count wherever both exist; 31 input embedding in the mode's own precision; 36 fp32-grade Linears on the register-staged
- * kernel, 37-39 ring depths of the LDS-DMA fp32-grade kernel.
+ * kernel, 37-39 ring depths of the LDS-DMA fp32-grade kernel; fp32-grade fusions: 52 attention chain / 56 cross-attention chains as
+ * separate launches, 58 the fused stylization on 64-row tiles, 60 stylization input and its Linear as two launches, 61 the
+ * LayerNorms / block tails behind it as their own launches, 62 fp32 rows instead of pre-split rows between the bf16x3 GEMMs;
+ * streamed-weight GEMM (MdmGemmDesc.w_stream): 63 never, 68 wherever eligible, 64-67 the same with a forced tile shape (112 x 512,
+ * 64 x 512, 64 x 256, 32 x 256).
  * 41-49 (timing-only knock-outs and the stamped build of the fused expert MLP: outputs are WRONG under them) exist only in the
  * diagnostic library (-DMDM_DIAG: `python motiondiffusion-moe_amd/build.py --diag` -> libmdm_hip_diag.so, used by tools/mlp_ko.py
  * and tools/mlp_stamps.py); libmdm_hip.so returns MDM_ERR_ARG for them and leaves the knob unchanged. */

@@ -100,6 +100,12 @@ int mdm_gemm_stream_pack(const float* w, int32_t N, int32_t K, int32_t h16, uint
   return mdm::gemm_stream_pack(w, N, K, h16, out, (hipStream_t)stream);
 }
 
+int64_t mdm_gemm_stream1_elems(int32_t N, int32_t K) { return mdm::gemm_stream1_elems(N, K); }
+
+int mdm_gemm_stream1_pack(const float* w, int64_t ldw, int32_t N, int32_t K, int32_t h16, uint16_t* out, void* stream) {
+  return mdm::gemm_stream1_pack(w, ldw, N, K, h16, out, (hipStream_t)stream);
+}
+
 int64_t mdm_gemm_stream3_elems(int32_t N, int32_t K) { return mdm::gemm_stream3_elems(N, K); }
 
 int mdm_gemm_stream3_pack(const float* w, int32_t N, int32_t K, uint16_t* out, void* stream) {

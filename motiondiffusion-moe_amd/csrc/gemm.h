@@ -60,6 +60,12 @@ bool gemm_x3_dma_eligible(const GemmArgs& a);
 int gemm_x3_dma(const GemmArgs& a, hipStream_t stream);  // gemm3.hip: bf16x3 with LDS-DMA staged fp32 activations
 bool gemm_fp8_eligible(const GemmArgs& a);
 int gemm_fp8(const GemmArgs& a, hipStream_t stream);  // gemm8.hip: e4m3 operands, block-scaled MFMA K = 128
+// gemm_stream.hip: plain Linear on 16-bit rows with the weight as a fragment stream (GemmArgs.w_stream)
+int64_t gemm_stream1_elems(int N, int K);
+int gemm_stream1_pack(const float* w, int64_t ldw, int N, int K, int h16, uint16_t* out, hipStream_t stream);
+bool gemm_stream1_eligible(const GemmArgs& a);
+bool gemm_stream1_wanted(const GemmArgs& a);  // eligible and measured faster than the tile kernel at this shape / epilogue
+int gemm_stream1(const GemmArgs& a, hipStream_t stream);
 // mlp_stream.hip: the same MLP with the weights streamed global -> registers from a packed fragment stream
 bool fused_mlp_stream_supported(const MdmMlpDesc& a);
 int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream);

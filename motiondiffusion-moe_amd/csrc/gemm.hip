@@ -372,7 +372,13 @@ int gemm(const GemmArgs& a_in, hipStream_t stream) {
     return gemm_fp8(a, stream);
   }
   if (a.K <= 0 || !a.A.p || !a.W.p || (!a.C && !a.C16 && !a.Cx2)) return MDM_ERR_ARG;
-  if (a.A.kind == OP_BF16_ROW) return gemm_bf16(a, stream);  // bf16 activations: throughput kernel (gemm2.hip)
+  if (a.A.kind == OP_BF16_ROW) {
+    // a Linear that carries a weight stream: streamed-weight kernel (gemm_stream.hip); knob 63: the tile kernel as before
+    // (knob 68: wherever it is eligible, not only where it was measured faster)
+    if (a.w_stream && g_bf16_variant != 63 && (g_bf16_variant >= 64 && g_bf16_variant <= 68 ? gemm_stream1_eligible(a) : gemm_stream1_wanted(a)))
+      return gemm_stream1(a, stream);
+    return gemm_bf16(a, stream);  // bf16 activations: throughput kernel (gemm2.hip)
+  }
   if (a.precision != 1 && a.precision != 3) return MDM_ERR_ARG;
   if (a.W.kind == OP_BF16_ROW) {
     if ((a.W.ld & 31) || (((uintptr_t)a.W.p) & 15) || (a.W.bs1 & 7) || (a.W.bs2 & 7)) return MDM_ERR_ARG;

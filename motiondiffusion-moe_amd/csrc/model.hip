@@ -174,6 +174,7 @@ int linear(const Ctx& c, Act A, int64_t M, int K, const MdmPacked& W, const floa
     if (A.x2) g.A.kind = OP_X2_ROW;
   }
   g.W = packed(W);
+  g.w_stream = A.bf ? W.ws : nullptr;  // 16-bit rows and a fragment stream of W: the streamed-weight kernel where it is eligible (csrc/gemm_stream.hip)
   g.M = (int)M, g.N = N, g.K = K;
   g.C = out32, g.C16 = out16, g.ldc = N;
   g.Cx2 = o.outx2;

@@ -87,9 +87,10 @@ def run_gemm(d: L.GemmDesc):
 def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
            alpha: float = 1.0, out_scale: float = 1.0, colscale=None, rowscale=None, r1=None, r1_scale: float = 1.0,
            r1_mod: int = 0, r2=None, precision: int = 3, out: Optional[torch.Tensor] = None,
-           out16: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out16: Optional[torch.Tensor] = None, w_stream: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = epilogue(x @ w^T): the fused Linear used throughout the denoiser.  bf16 ``x`` selects the throughput
-    kernel (gemm2.hip); ``out16`` receives an optional bf16 copy of the result."""
+    kernel (gemm2.hip); ``out16`` receives an optional bf16 copy of the result; ``w_stream`` (gemm_stream1_pack of the same
+    weight) lets an eligible 16-bit launch run on the streamed-weight kernel (gemm_stream.hip)."""
     L.require_cuda(x)
     K = x.shape[-1]
     assert K == w.K, (K, w.K)
@@ -106,6 +107,7 @@ def linear(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None
     else:
         d.A = f32_operand(x2, x2.stride(0))
     d.W = w.operand()
+    d.w_stream = L.ptr(w_stream)
     d.M, d.N, d.K = M, w.N, K
     d.C, d.ldc = out.data_ptr(), out.stride(0)
     if out16 is not None:
@@ -196,6 +198,23 @@ def gemm_stream_pack(w: torch.Tensor, dtype: torch.dtype) -> Optional[torch.Tens
         L.check(L.lib().mdm_gemm_stream_pack(C.c_void_p(w.data_ptr()), C.c_int32(N), C.c_int32(K),
                                              C.c_int32(L.H16_F16 if dtype == torch.float16 else L.H16_BF16),
                                              C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr())), "mdm_gemm_stream_pack")
+    return out
+
+
+def gemm_stream1_pack(w: torch.Tensor, dtype: torch.dtype) -> Optional[torch.Tensor]:
+    """Fragment stream of one fp32 Linear [N, K] for the streamed-weight GEMM of the 16-bit modes (csrc/gemm_stream.hip;
+    MdmGemmDesc.w_stream / MdmPacked.ws); None when the shape is not covered (N % 256, K % 256)."""
+    L.require_cuda(w)
+    N, K = w.shape
+    n = L.lib().mdm_gemm_stream1_elems(C.c_int32(N), C.c_int32(K))
+    if n <= 0:
+        return None
+    w = w.detach().to(torch.float32).contiguous()
+    out = torch.empty(n, dtype=dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(L.lib().mdm_gemm_stream1_pack(C.c_void_p(w.data_ptr()), C.c_int64(K), C.c_int32(N), C.c_int32(K),
+                                              C.c_int32(L.H16_F16 if dtype == torch.float16 else L.H16_BF16),
+                                              C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr())), "mdm_gemm_stream1_pack")
     return out
 
 

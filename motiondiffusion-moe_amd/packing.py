@@ -217,6 +217,21 @@ class PackedModel:
                         ws = gemm_stream3_pack(lay["W:" + st + "out"].to(dev))
                         if ws is not None:
                             self.wstream[st + "out3"] = ws
+            # fragment streams of the plain per-layer Linears for the streamed-weight GEMM (csrc/gemm_stream.hip): the 16-bit modes of the
+            # big model, whose D x D launches are latency chains on the tile kernel; MDM_GEMM_STREAM=0 keeps the tile kernel (A/B runs)
+            self.wstream1 = {}
+            if (os.environ.get("MDM_GEMM_STREAM", "1") != "0" and D == 1024
+                    and precision in (L.PREC_BF16, L.PREC_F16, L.PREC_FP8)):
+                from .ops import gemm_stream1_pack
+                for kk, t in lay.items():
+                    if not kk.startswith("W:L") or t.dim() != 2 or t.shape[1] not in (512, 1024) or t.shape[0] % 256:
+                        continue
+                    fmt = weight_format(kk[2:], precision, head_dim)
+                    if fmt not in ("f16", "bf16", "bf16x2"):
+                        continue
+                    ws = gemm_stream1_pack(t.to(dev), torch.float16 if fmt == "f16" else torch.bfloat16)
+                    if ws is not None:
+                        self.wstream1[kk[2:]] = ws
             self.layers = (L.Layer * (2 * L_))()
             for li, (pre, tag) in enumerate(layer_tags(L_)):
                 self._fill_layer(self.layers[li], f"L{li}.", pre, counters)
@@ -240,6 +255,8 @@ class PackedModel:
         w = self.W[name]
         p = L.Packed()
         p.hi, p.lo, p.ld = w.hi.data_ptr(), (w.lo.data_ptr() if w.lo is not None else 0), w.Kp
+        if name in getattr(self, "wstream1", {}):
+            p.ws = self.wstream1[name].data_ptr()
         return p
 
     def _style(self, st: L.Style, pre: str):

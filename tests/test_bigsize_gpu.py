@@ -313,3 +313,29 @@ def test_big_width_router_with_compile_time_expert_count_is_bit_identical(precis
     assert torch.isfinite(outs[26]).all()
     assert torch.equal(outs[26], outs[27]), float((outs[26] - outs[27]).abs().max())
     assert torch.equal(default, outs[27])
+
+
+@pytest.mark.parametrize("precision", [2, 1])
+def test_big_width_streamed_weight_linears_compute_the_tile_kernels_function(precision):
+    """csrc/gemm_stream.hip inside the model (MdmPacked.ws: the per-layer D x D Linears of the 16-bit modes at D = 1024) against the
+    same forward on the tile kernel (knob 63).  Same MFMA, operand order and k order; with general epilogue scales the two differ
+    in the last fp32 bit (7e-8 relative, tests/test_gemm_gpu.py), which a 16-bit store may round either way: gated at 16-bit noise."""
+    L_ = pkg("_lib")
+    m, _ = _big(precision)
+    assert m.pack().wstream1, "the big model packs fragment streams for its D x D Linears"
+    B, T = 4, 64
+    x, length, xf_proj, xf_out = _inputs(B, T)
+    length = length.clamp(max=T)
+    t = torch.full((B,), 500, dtype=torch.int64)
+    args = (x.cuda(), t.cuda(), length.cuda())
+    kw = dict(xf_proj=xf_proj.cuda(), xf_out=xf_out.cuda())
+    y = m(*args, **kw).cpu()
+    L_.lib().mdm_set_gemm_variant(63)
+    try:
+        yt = m(*args, **kw).cpu()
+    finally:
+        L_.lib().mdm_set_gemm_variant(0)
+    frame = (y - yt).abs().amax(-1) / yt.abs().max()
+    print(f"big precision {precision}: streamed vs tile Linears, median frame difference {float(frame.median()):.2e}, max {float(frame.max()):.2e}")
+    assert torch.isfinite(y).all()  # (with the model's epilogues -- alpha = r1_scale = 1 -- the two kernels may agree bit for bit)
+    assert float(frame.median()) < (2e-3 if precision == 2 else 1.5e-2)

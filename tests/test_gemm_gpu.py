@@ -439,3 +439,59 @@ def test_x3_gemm_on_pre_split_rows_is_bit_identical(M, N, K, grouped):
         ops.run_gemm(e)
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,act", [(12544, 1024, 1024, 1), (6272, 1024, 1024, 0), (3136, 1024, 1024, 0), (1568, 1024, 1024, 1),
+                                       (1000, 1024, 1024, 0), (50, 512, 1024, 1), (1, 256, 512, 0), (12544, 512, 512, 0),
+                                       (777, 3072, 1024, 0), (12544, 4096, 1024, 1)])
+def test_streamed_weight_gemm(M, N, K, act, fmt):
+    """csrc/gemm_stream.hip (MdmGemmDesc.w_stream): the weight as a fragment stream global -> registers, the 16-bit rows through LDS
+    in K slices; every tile shape the launcher picks (112 / 64 / 32 rows, 512 / 256 columns), ragged last row tiles, both 16-bit
+    formats, the whole epilogue.  Against fp64 of the same rounded operands, and against the tile kernel (knob 63) it replaces."""
+    L, ops = _mods()
+    dt = torch.float16 if fmt == "f16" else torch.bfloat16
+    x, w, b = _rand(M, K, seed=41), _rand(N, K, seed=42) * K ** -0.5 * 4, _rand(N, seed=43)
+    xb = x.to(dt)
+    pw = ops.PackedWeight(w, fmt=fmt)
+    ws = ops.gemm_stream1_pack(w, dt)
+    assert ws is not None and ws.numel() >= N * K + 16 * 512
+    r1, cs = _rand(M, N, seed=44), _rand(N, seed=45)
+    kw = dict(act=L.ACT_GELU if act else L.ACT_NONE, alpha=0.9, out_scale=0.5, colscale=cs, r1=r1, r1_scale=0.3, precision=1)
+    o16s, o16t = torch.empty(M, N, dtype=dt, device="cuda"), torch.empty(M, N, dtype=dt, device="cuda")
+    L.lib().mdm_set_gemm_variant(68)  # the streamed kernel wherever it is eligible (by default: only where it measured faster)
+    try:
+        y = ops.linear(xb, pw, b, out16=o16s, w_stream=ws, **kw)
+        y2 = ops.linear(xb, pw, None, precision=1, w_stream=ws)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    L.lib().mdm_set_gemm_variant(63)
+    try:
+        yt = ops.linear(xb, pw, b, out16=o16t, w_stream=ws, **kw)
+    finally:
+        L.lib().mdm_set_gemm_variant(0)
+    pre = 0.9 * (xb.double() @ w.to(dt).double().T + b.double())
+    ref = (torch.nn.functional.gelu(pre) if act else pre) * 0.5 * cs.double()[None] + 0.3 * r1.double()
+    e_ref, e_tile = rel_inf(y.cpu(), ref.float().cpu()), rel_inf(y.cpu(), yt.cpu())
+    print(f"M={M} N={N} K={K} act={act} {fmt}: vs fp64 {e_ref:.2e}, vs the tile kernel {e_tile:.2e} (equal: {torch.equal(y, yt)})")
+    assert e_ref < 1e-4 and e_tile < 2e-6
+    assert torch.equal(o16s, y.to(dt))
+    # outputs one at a time, no residual / scales: the optional pointers of the epilogue
+    assert rel_inf(y2.cpu(), (xb.double() @ w.to(dt).double().T).float().cpu()) < 1e-4
+
+
+def test_streamed_weight_gemm_is_only_taken_where_it_applies():
+    """A launch the streamed kernel does not cover (row scales, K outside {512, 1024}, fp32 rows) runs on the tile kernels as if no
+    stream had been given."""
+    L, ops = _mods()
+    M, N, K = 300, 512, 1024
+    x, w = _rand(M, K, seed=51), _rand(N, K, seed=52)
+    pw, ws = ops.PackedWeight(w), ops.gemm_stream1_pack(w, torch.bfloat16)
+    rs = _rand(M, seed=53)
+    a = ops.linear(x.to(torch.bfloat16), pw, None, rowscale=rs, precision=1, w_stream=ws)
+    b = ops.linear(x.to(torch.bfloat16), pw, None, rowscale=rs, precision=1)
+    assert torch.equal(a, b)
+    a = ops.linear(x, pw, None, precision=3, w_stream=ws)
+    b = ops.linear(x, pw, None, precision=3)
+    assert torch.equal(a, b)
+    assert ops.gemm_stream1_pack(_rand(200, 512, seed=54), torch.bfloat16) is None

@@ -18,7 +18,8 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(tr)):
     n = r['Kernel_Name']
     if 'gemm' not in n: continue
-    k = re.search(r'gemm\w*<[^>]*>', n).group(0)
+    mm = re.search(r'gemm\w*<[^>]*>', n) or re.search(r'\w*gemm\w*', n)  # (the pack kernels have no template arguments)
+    k = mm.group(0)
     key = (k, int(r['Grid_Size_X']) // 256, int(r['Grid_Size_Z']))
     agg[key][0] += 1; agg[key][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 gt = sum(v[1] for v in agg.values())
