@@ -39,12 +39,24 @@ PEAK = {1: 2.5e15, 2: 2.5e15, 3: 2.5e15 / 3, 4: 2.5e15 / (0.48 * 3 + 0.52), 5: 1
 DTYPE = {1: "bf16", 2: "f16", 3: "bf16x3(fp32-grade)", 4: "mixed(bf16x3 + f16 expert/FFN GEMMs)", 5: "f16 + fp8(e4m3) expert GEMMs"}
 
 
+_SD_CACHE = {}  # (config, seed) -> synthetic state dict of the LAST config built (the big models' take 15 - 25 s of host time each)
+
+
 def build_model(cfg_name, device, precision, B, T, N, seed=0, N_u=None):
     T_ = importlib.import_module("motiondiffusion-moe_amd.transformer")
     synth = importlib.import_module("motiondiffusion-moe_amd.synth")
     kw, _, _ = CONFIGS[cfg_name]
-    m = T_.MotionTransformer(263, num_frames=196, precision=precision, **kw)
-    sd = synth.synth_state_dict(m._layout, seed)
+    # every parameter is overwritten by the synthetic state dict below: skip the constructor's random init (15 s for the big model)
+    reset = T_.MotionTransformer.reset_parameters
+    T_.MotionTransformer.reset_parameters = lambda self: None
+    try:
+        m = T_.MotionTransformer(263, num_frames=196, precision=precision, **kw)
+    finally:
+        T_.MotionTransformer.reset_parameters = reset
+    if (cfg_name, seed) not in _SD_CACHE:
+        _SD_CACHE.clear()
+        _SD_CACHE[(cfg_name, seed)] = synth.synth_state_dict(m._layout, seed)
+    sd = _SD_CACHE[(cfg_name, seed)]
     m.load_state_dict(sd, strict=True)
     D, Dt, L = m.latent_dim, m.text_latent_dim, m.num_layers
     eph = synth.synth_ephemerals(D, Dt, L, 7)
