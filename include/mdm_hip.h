@@ -114,6 +114,10 @@ typedef struct MdmGemmDesc {
    * groups / gather, act NONE or GELU, N % 256 == K % 256 == 0) then runs on the streamed-weight kernel (csrc/gemm_stream.hip);
    * anything else ignores it */
   const uint16_t* w_stream;
+  /* fp32-grade mode (precision 3) with MDM_OP_X2_ROW activations: w_stream = the (bf16 hi, lo) fragment-pair stream of W
+   * (mdm_gemm_stream3x_pack; K in {512, 1024}, N % 512 == 0) selects the streamed-weight bf16x3 kernel (csrc/gemm_stream3.hip);
+   * grouped launches (goff) give the stream's elements per group (mdm_gemm_stream3x_elems(1, N, K) minus the tail pad) here */
+  int64_t w_stream_gs;
 } MdmGemmDesc;
 
 int mdm_gemm(const MdmGemmDesc* desc, void* stream);
@@ -172,6 +176,11 @@ int mdm_gemm_stream_pack(const float* w, int32_t N, int32_t K, int32_t h16, uint
  * MFMA operand fragments of 1 KiB in the 16-bit format h16, plus the read-ahead pad.  elems: 16-bit elements to allocate, 0 when the
  * shape is not covered (N % 256, K % 256). */
 int64_t mdm_gemm_stream1_elems(int32_t N, int32_t K);
+/* ... and of G stacked [N, K] fp32 weights (the experts of one layer) as (bf16 hi, lo) fragment PAIRS for the streamed-weight
+ * bf16x3 GEMM (MdmGemmDesc.w_stream with MDM_OP_X2_ROW activations); group_elems = the stride between groups (w_stream_gs) */
+int64_t mdm_gemm_stream3x_elems(int32_t G, int32_t N, int32_t K);
+int64_t mdm_gemm_stream3x_group_elems(int32_t N, int32_t K);
+int mdm_gemm_stream3x_pack(const float* w, int64_t ldw, int32_t G, int32_t N, int32_t K, uint16_t* out, void* stream);
 int mdm_gemm_stream1_pack(const float* w, int64_t ldw, int32_t N, int32_t K, int32_t h16, uint16_t* out, void* stream);
 
 /* the same for the fp32-grade (bf16x3) form of that kernel: (bf16 hi, lo = rn(w - hi)) fragment PAIRS in consumption order,
@@ -452,7 +461,7 @@ int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
  * separate launches, 58 the fused stylization on 64-row tiles, 60 stylization input and its Linear as two launches, 61 the
  * LayerNorms / block tails behind it as their own launches, 62 fp32 rows instead of pre-split rows between the bf16x3 GEMMs;
  * streamed-weight GEMM (MdmGemmDesc.w_stream): 63 never, 68 wherever eligible, 64-67 the same with a forced tile shape (112 x 512,
- * 64 x 512, 64 x 256, 32 x 256).
+ * 64 x 512, 64 x 256, 32 x 256); its bf16x3 form (pre-split rows x a pair stream): 69 never, 70 wherever eligible.
  * 41-49 (timing-only knock-outs and the stamped build of the fused expert MLP: outputs are WRONG under them) exist only in the
  * diagnostic library (-DMDM_DIAG: `python motiondiffusion-moe_amd/build.py --diag` -> libmdm_hip_diag.so, used by tools/mlp_ko.py
  * and tools/mlp_stamps.py); libmdm_hip.so returns MDM_ERR_ARG for them and leaves the knob unchanged. */

@@ -41,7 +41,7 @@ class GemmDesc(C.Structure):
                 ("feat_rpt", C.c_int32), ("feat_kslot", C.c_int32), ("precision", C.c_int32), ("h16", C.c_int32),
                 ("a_scale", C.c_void_p), ("w_scale", C.c_void_p), ("a_scale_u", C.c_float), ("C8", C.c_void_p),
                 ("c8_scale", C.c_float), ("kgoff", C.c_void_p), ("hn_w", C.c_void_p), ("hn_b", C.c_void_p),
-                ("C16_lo", C.c_void_p), ("hn_l2_tiles", C.c_int32), ("Cx2", C.c_void_p), ("w_stream", C.c_void_p)]
+                ("C16_lo", C.c_void_p), ("hn_l2_tiles", C.c_int32), ("Cx2", C.c_void_p), ("w_stream", C.c_void_p), ("w_stream_gs", C.c_int64)]
 
 
 class MoeTensors(C.Structure):
@@ -133,7 +133,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.mdm_version.restype = C.c_char_p
         for name in EXPORTS:
-            if name in ("mdm_workspace_bytes", "mdm_text_head_workspace_bytes", "mdm_moe_train_workspace_bytes", "mdm_mlp_stream_elems", "mdm_gemm_stream_elems", "mdm_gemm_stream3_elems", "mdm_gemm_stream1_elems"):
+            if name in ("mdm_workspace_bytes", "mdm_text_head_workspace_bytes", "mdm_moe_train_workspace_bytes", "mdm_mlp_stream_elems", "mdm_gemm_stream_elems", "mdm_gemm_stream3_elems", "mdm_gemm_stream1_elems", "mdm_gemm_stream3x_elems", "mdm_gemm_stream3x_group_elems"):
                 getattr(L, name).restype = C.c_int64
             elif name != "mdm_version":
                 getattr(L, name).restype = C.c_int
@@ -142,7 +142,7 @@ def lib():
 
 
 # every symbol include/mdm_hip.h declares (checked by tests/test_abi.py)
-EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_mlp_stream_elems", "mdm_mlp_stream_pack", "mdm_gemm_stream_elems", "mdm_gemm_stream_pack", "mdm_gemm_stream3_elems", "mdm_gemm_stream3_pack", "mdm_gemm_stream1_elems", "mdm_gemm_stream1_pack", "mdm_pack_bf16", "mdm_pack_f16", "mdm_pack_fp8", "mdm_workspace_bytes", "mdm_text_cache_build",
+EXPORTS = ["mdm_version", "mdm_gemm", "mdm_fused_mlp", "mdm_mlp_stream_elems", "mdm_mlp_stream_pack", "mdm_gemm_stream_elems", "mdm_gemm_stream_pack", "mdm_gemm_stream3_elems", "mdm_gemm_stream3_pack", "mdm_gemm_stream1_elems", "mdm_gemm_stream1_pack", "mdm_gemm_stream3x_elems", "mdm_gemm_stream3x_group_elems", "mdm_gemm_stream3x_pack", "mdm_pack_bf16", "mdm_pack_f16", "mdm_pack_fp8", "mdm_workspace_bytes", "mdm_text_cache_build",
            "mdm_denoiser_forward", "mdm_stem_cache_build", "mdm_block_forward", "mdm_moe_ffn_forward", "mdm_dual_self_attn_forward", "mdm_linear_xattn_forward",
            "mdm_softmax_xattn_ffn_forward", "mdm_performer_attn_forward", "mdm_stylization_forward", "mdm_stem_embeddings",
            "mdm_cfg_posterior_step", "mdm_ddim_step", "mdm_noise_normal", "mdm_noise_normal_ids", "mdm_text_head_workspace_bytes", "mdm_text_head_forward", "mdm_motion_postprocess", "mdm_xattn_gate", "mdm_fill_i64", "mdm_add_i32", "mdm_set_gemm_variant", "mdm_diag_build", "mdm_diag_mlp_counters", "mdm_debug_stamps", "mdm_probe_enable", "mdm_probe_read", "mdm_route_dump",

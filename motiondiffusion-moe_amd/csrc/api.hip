@@ -106,6 +106,14 @@ int mdm_gemm_stream1_pack(const float* w, int64_t ldw, int32_t N, int32_t K, int
   return mdm::gemm_stream1_pack(w, ldw, N, K, h16, out, (hipStream_t)stream);
 }
 
+int64_t mdm_gemm_stream3x_elems(int32_t G, int32_t N, int32_t K) { return mdm::gemm_stream3x_elems(G, N, K); }
+
+int64_t mdm_gemm_stream3x_group_elems(int32_t N, int32_t K) { return mdm::gemm_stream3x_group_elems(N, K); }
+
+int mdm_gemm_stream3x_pack(const float* w, int64_t ldw, int32_t G, int32_t N, int32_t K, uint16_t* out, void* stream) {
+  return mdm::gemm_stream3x_pack(w, ldw, G, N, K, out, (hipStream_t)stream);
+}
+
 int64_t mdm_gemm_stream3_elems(int32_t N, int32_t K) { return mdm::gemm_stream3_elems(N, K); }
 
 int mdm_gemm_stream3_pack(const float* w, int32_t N, int32_t K, uint16_t* out, void* stream) {

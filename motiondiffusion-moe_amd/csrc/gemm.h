@@ -66,6 +66,13 @@ int gemm_stream1_pack(const float* w, int64_t ldw, int N, int K, int h16, uint16
 bool gemm_stream1_eligible(const GemmArgs& a);
 bool gemm_stream1_wanted(const GemmArgs& a);  // eligible and measured faster than the tile kernel at this shape / epilogue
 int gemm_stream1(const GemmArgs& a, hipStream_t stream);
+// gemm_stream3.hip: the same in bf16x3 on pre-split rows, dense or grouped + gathered (the fp32-grade expert GEMMs)
+int64_t gemm_stream3x_elems(int G, int N, int K);
+int64_t gemm_stream3x_group_elems(int N, int K);
+int gemm_stream3x_pack(const float* w, int64_t ldw, int G, int N, int K, uint16_t* out, hipStream_t stream);
+bool gemm_stream3x_eligible(const GemmArgs& a);
+bool gemm_stream3x_wanted(const GemmArgs& a);  // eligible and measured faster than the tile kernel of gemm3.hip
+int gemm_stream3x(const GemmArgs& a, hipStream_t stream);
 // mlp_stream.hip: the same MLP with the weights streamed global -> registers from a packed fragment stream
 bool fused_mlp_stream_supported(const MdmMlpDesc& a);
 int fused_mlp_stream(const MdmMlpDesc& a, hipStream_t stream);

@@ -388,6 +388,10 @@ int gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.A.kind == OP_BF16_ROW) return MDM_ERR_UNSUPPORTED;
   if (a.goff && (a.batch != 1 || a.ngroups <= 0)) return MDM_ERR_ARG;
   if (a.kgoff && (a.goff || a.A.kind != OP_F32_KSTRIDE || a.W.kind != OP_F32_KSTRIDE)) return MDM_ERR_ARG;
+  // pre-split rows x a (hi, lo) pair stream: streamed-weight bf16x3 kernel (gemm_stream3.hip) where it measured faster; knob 69: the
+  // tile kernel as before, 70: the streamed kernel wherever it is eligible
+  if (a.w_stream && a.A.kind == OP_X2_ROW && g_bf16_variant != 69 && (g_bf16_variant == 70 ? gemm_stream3x_eligible(a) : gemm_stream3x_wanted(a)))
+    return gemm_stream3x(a, stream);
   // plain Linears of the fp32-grade mode: LDS-DMA staged bf16x3 kernel (gemm3.hip); knob 36 keeps the register-staged one
   if ((g_bf16_variant != 36 || a.act == ACT_HEADNORM || a.act == ACT_HEADSOFTMAX || a.C16_lo || a.Cx2 || a.A.kind == OP_X2_ROW) &&
       gemm_x3_dma_eligible(a))

@@ -586,6 +586,7 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     g.act = ACT_GELU;
     g.C = (h || hx2) ? nullptr : w.hid, g.C16 = h ? (uint16_t*)w.hid : nullptr, g.ldc = F;
     if (hx2) g.Cx2 = (uint16_t*)w.hid;
+    if (hx2 && l.w1.ws) g.w_stream = l.w1.ws, g.w_stream_gs = gemm_stream3x_group_elems(F, D);  // streamed-weight bf16x3 kernel (csrc/gemm_stream3.hip)
     MDM_TRY(gemm(g, c.s));
   }
   {
@@ -603,6 +604,7 @@ int moe_block(const Ctx& c, const MdmLayer& l, const float* x, const float* sc, 
     g.bias = l.b2, g.bias_bs = D;
     g.rowscale = w.rowscale;
     g.C = w.y2, g.ldc = D;  // fp32: the four routed rows of a token are summed in the stylization kernel
+    if (hx2 && l.w2.ws) g.w_stream = l.w2.ws, g.w_stream_gs = gemm_stream3x_group_elems(D, F);
     MDM_TRY(gemm(g, c.s));
   }
   if (pr2) {

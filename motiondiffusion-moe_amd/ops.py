@@ -218,6 +218,23 @@ def gemm_stream1_pack(w: torch.Tensor, dtype: torch.dtype) -> Optional[torch.Ten
     return out
 
 
+def gemm_stream3x_pack(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """(bf16 hi, lo) fragment-pair stream of G stacked fp32 Linears [G, N, K] (or one [N, K]) for the streamed-weight bf16x3 GEMM
+    (csrc/gemm_stream3.hip; MdmGemmDesc.w_stream with pre-split activation rows); None when the shape is not covered."""
+    L.require_cuda(w)
+    w3 = w if w.dim() == 3 else w[None]
+    G, N, K = w3.shape
+    n = L.lib().mdm_gemm_stream3x_elems(C.c_int32(G), C.c_int32(N), C.c_int32(K))
+    if n <= 0:
+        return None
+    w3 = w3.detach().to(torch.float32).contiguous()
+    out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(L.lib().mdm_gemm_stream3x_pack(C.c_void_p(w3.data_ptr()), C.c_int64(K), C.c_int32(G), C.c_int32(N), C.c_int32(K),
+                                               C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr())), "mdm_gemm_stream3x_pack")
+    return out
+
+
 def gemm_stream3_pack(w: torch.Tensor) -> Optional[torch.Tensor]:
     """(bf16 hi, lo) fragment-pair stream of one fp32 Linear [N, K] for the fp32-grade form of the fused stylization kernel
     (csrc/style_gemm.hip style_gemm3); None when the shape is not taken (N = K = 512 only)."""

@@ -232,6 +232,18 @@ class PackedModel:
                     ws = gemm_stream1_pack(t.to(dev), torch.float16 if fmt == "f16" else torch.bfloat16)
                     if ws is not None:
                         self.wstream1[kk[2:]] = ws
+            # (hi, lo) fragment-pair streams of the expert matrices for the streamed-weight bf16x3 GEMM (csrc/gemm_stream3.hip): the
+            # fp32-grade mode, whose expert GEMM pair is 45 % of its step on the tile kernel
+            if os.environ.get("MDM_GEMM_STREAM", "1") != "0" and with_lo and precision == L.PREC_X3 and D % 128 == 0 and F_ % 128 == 0:
+                from .ops import gemm_stream3x_pack
+                for li in range(2 * L_):
+                    k = f"L{li}."
+                    for name, shape in ((k + "w1", (E2, F_, D)), (k + "w2", (E2, D, F_))):
+                        if weight_format(name, precision, head_dim) != "bf16x2":
+                            continue
+                        ws = gemm_stream3x_pack(lay["W:" + name].to(dev).reshape(*shape))
+                        if ws is not None:
+                            self.wstream1[name] = ws
             self.layers = (L.Layer * (2 * L_))()
             for li, (pre, tag) in enumerate(layer_tags(L_)):
                 self._fill_layer(self.layers[li], f"L{li}.", pre, counters)

@@ -495,3 +495,67 @@ def test_streamed_weight_gemm_is_only_taken_where_it_applies():
     b = ops.linear(x, pw, None, precision=3)
     assert torch.equal(a, b)
     assert ops.gemm_stream1_pack(_rand(200, 512, seed=54), torch.bfloat16) is None
+
+
+def _x2_rows(x):
+    """fp32 [M, K] -> MDM_OP_X2_ROW rows [M, 2 K] bf16 (per 32 columns: 32 hi then 32 lo = rn(x - hi))."""
+    M, K = x.shape
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi.reshape(M, K // 32, 32), lo.reshape(M, K // 32, 32)], 2).reshape(M, 2 * K).contiguous()
+
+
+@pytest.mark.parametrize("sizes,N,K,act,gathered", [([3136] * 16, 1024, 512, 1, True), ([3136] * 16, 512, 1024, 0, False),
+                                                    ([200, 0, 315, 112, 1, 113], 1024, 512, 1, True),
+                                                    ([200, 0, 315, 112, 1, 113], 512, 1024, 0, False), ([777], 512, 512, 0, False),
+                                                    ([5], 1024, 1024, 1, True)])
+def test_streamed_weight_x3_gemm_is_bit_identical_to_the_tile_kernel(sizes, N, K, act, gathered):
+    """csrc/gemm_stream3.hip: pre-split rows x a (hi, lo) fragment-pair stream, dense and grouped (empty, 1-row and ragged groups),
+    with a row gather, GELU -> pre-split rows out (the expert W1 launch) and row scale -> fp32 out (W2).  Same products in the same
+    order as the 128 x 128 tile kernel of csrc/gemm3.hip (knob 69): every output bit must agree; and against fp64."""
+    L, ops = _mods()
+    G, M = len(sizes), sum(sizes)
+    S = max(M // 3, 8)  # source rows the gather draws from
+    x = _rand(S if gathered else M, K, seed=61)
+    w, b = _rand(G, N, K, seed=62) * K ** -0.5, _rand(G, N, seed=63)
+    rs = _rand(M, seed=64).abs() + 0.1
+    xx2 = _x2_rows(x)
+    pw = ops.PackedWeight(w if G > 1 else w[0])
+    ws = ops.gemm_stream3x_pack(w)
+    assert ws is not None
+    goff = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device="cuda")
+    gather = torch.randint(0, S, (M,), generator=torch.Generator().manual_seed(7), dtype=torch.int32).cuda() if gathered else None
+    outs = []
+    for knob in (70, 69):  # 70: the streamed kernel wherever it is eligible (by default only where it measured faster)
+        d = ops.gemm_desc(3)
+        d.A = ops.f32_operand(xx2.view(torch.float32), K)  # ld in 4-byte units
+        d.A.kind, d.A.gather = L.OP_X2_ROW, L.ptr(gather)
+        d.W = pw.operand()
+        d.w_stream = ws.data_ptr()
+        d.M, d.N, d.K = M, N, K
+        d.bias, d.act = b.data_ptr(), (L.ACT_GELU if act else L.ACT_NONE)
+        if G > 1:
+            d.goff, d.ngroups, d.W.bs1, d.bias_bs = goff.data_ptr(), G, N * pw.Kp, N
+            d.w_stream_gs = L.lib().mdm_gemm_stream3x_group_elems(C.c_int32(N), C.c_int32(K))
+        out, ox2 = torch.zeros(M, N, device="cuda"), torch.zeros(M, 2 * N, dtype=torch.bfloat16, device="cuda")
+        d.C, d.ldc = out.data_ptr(), N
+        if act:
+            d.Cx2 = ox2.data_ptr()
+        else:
+            d.rowscale = rs.data_ptr()
+        L.lib().mdm_set_gemm_variant(knob)
+        try:
+            ops.run_gemm(d)
+        finally:
+            L.lib().mdm_set_gemm_variant(0)
+        outs.append((out, ox2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    xs = (x[gather.long()] if gathered else x).double()
+    ref = torch.empty(M, N, dtype=torch.float64, device="cuda")
+    for gi in range(G):
+        r = slice(int(goff[gi]), int(goff[gi + 1]))
+        ref[r] = xs[r] @ w[gi].double().T + b[gi].double()
+    ref = torch.nn.functional.gelu(ref) if act else ref * rs.double()[:, None]
+    assert rel_inf(outs[0][0].cpu(), ref.float().cpu()) < 2e-5
+    if act:
+        assert torch.equal(outs[0][1].view(torch.int16), _x2_rows(outs[0][0]).view(torch.int16))
