@@ -197,6 +197,13 @@ __global__ __launch_bounds__(G3_NT, 2) void gemm_stream3_kernel(const G3Args g) 
     const f32x4 q = g.colscale ? *(const f32x4*)(g.colscale + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
     cs[j] = (f32x4){g.out_scale * q[0], g.out_scale * q[1], g.out_scale * q[2], g.out_scale * q[3]};
   }
+  float rsv[RT];  // row scales of this lane's RT rows, requested together
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    int64_t m = row0 + i * 16 + frow;
+    m = m < row_end ? m : row_end - 1;
+    rsv[i] = g.rowscale ? g.rowscale[m] : 1.f;
+  }
   constexpr int NB = 128 * NJ, EPT = (SMEM / (64 * NB)) < RT ? (SMEM / (64 * NB)) : RT, NPASS = (RT + EPT - 1) / EPT;
   constexpr int TPR = NB / 4, RPS = G3_NT / TPR, NK = 16 * EPT / RPS;  // threads per row, rows per step, steps per pass
   float* const stg = (float*)smem;
@@ -209,9 +216,7 @@ __global__ __launch_bounds__(G3_NT, 2) void gemm_stream3_kernel(const G3Args g) 
       const int i = p * EPT + ii;
       if (i < RT) {
         const int ml = ii * 16 + frow;
-        int64_t m = row0 + i * 16 + frow;
-        m = m < row_end ? m : row_end - 1;
-        const float rs = g.rowscale ? g.rowscale[m] : 1.f;
+        const float rs = rsv[i];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           f32x4 v;
@@ -228,6 +233,31 @@ __global__ __launch_bounds__(G3_NT, 2) void gemm_stream3_kernel(const G3Args g) 
       }
     }
     __syncthreads();
+    if (!g.R1 && !g.R2) {
+      // no residuals (both expert launches): nothing is loaded between the stores -- on gfx950 stores count in vmcnt too, so a wait for
+      // a residual row (even one that a null pointer skips) is a wait for every store issued before it: the general path below
+      // serialised the tile's 40 store batches on the write latency (80 of 199 us at 50 176 x 1024 x 512)
+      constexpr int KS = 4;  // staged rows read together, then stored
+      static_assert(NK % KS == 0, "row batches");
+#pragma unroll
+      for (int k0 = 0; k0 < NK; k0 += KS) {
+        f32x4 o[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const int ml = rq + RPS * (k0 + k);
+          o[k] = *(const f32x4*)(stg + ml * NB + ((cl ^ (ml & 31)) << 2));
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const int ml = rq + RPS * (k0 + k);
+          const int64_t m = row0 + p * EPT * 16 + ml;
+          if (p * EPT * 16 + ml >= 16 * RT || m >= row_end) continue;  // (whole rows: both lanes of a column pair agree)
+          if (g.C) *(f32x4*)(g.C + m * g.ldc + n) = o[k];
+          if (g.Cx2) store_x2_4p(g.Cx2 + m * 2 * g.ldc, n, o[k][0], o[k][1], o[k][2], o[k][3]);
+        }
+      }
+      continue;
+    }
     constexpr int KB = 2;
 #pragma unroll
     for (int k0 = 0; k0 < NK; k0 += KB) {
@@ -324,12 +354,12 @@ bool gemm_stream3x_eligible(const GemmArgs& a) {
   return a.M > 0 && (int64_t)a.M * a.N < (1ll << 40);
 }
 
-// Where it is the faster kernel (tools/x3_stream_bench.py, 16 balanced groups, same process): K = 1024 (the expert W2 launch:
-// 157 vs 181 us at 50 176 rows, 75 vs 91 us at 25 088 = 0.40 - 0.42 of the 833 TFLOP/s a bf16x3 product stream can reach) and the
-// K = 512 launch (W1 + GELU -> pre-split rows) below ~30 000 rows (100 vs 105 us at 25 088; at 50 176 rows 214 vs 204 us: with 16
-// K steps per tile the per-tile prologue and the staged GELU epilogue, which one workgroup per CU cannot overlap with the next
-// tile, weigh a quarter of the tile)
-bool gemm_stream3x_wanted(const GemmArgs& a) { return gemm_stream3x_eligible(a) && (a.K >= 1024 || a.M < 30000); }
+// Measured against the tile kernel (tools/x3_stream_bench.py, 16 balanced groups, same process, profiles/r04_x3_stream_bench.txt):
+// K = 1024 (expert W2) 146 vs 183 us at 50 176 rows, 70 vs 92 us at 25 088 = 0.43 - 0.45 of the 833 TFLOP/s a bf16x3 product stream
+// can reach; K = 512 (W1 + GELU -> pre-split rows) 190 vs 206 us and 89 vs 104 us (0.33 - 0.36: with 16 K steps per tile the
+// prologue and the staged GELU epilogue, which one workgroup per CU cannot overlap with the next tile, are a third of the tile).
+// Taken wherever it is eligible.
+bool gemm_stream3x_wanted(const GemmArgs& a) { return gemm_stream3x_eligible(a); }
 
 int gemm_stream3x(const GemmArgs& a, hipStream_t stream) {
   if (!gemm_stream3x_eligible(a)) return MDM_ERR_UNSUPPORTED;
