@@ -195,6 +195,47 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_stream_kernel(const GsArgs g) {
         for (int j = 0; j < NJ; ++j) *(f32x4*)(stg + ml * NB + (((wn * 4 * NJ + 4 * j + fq) ^ (ml & 31)) << 2)) = finish(i, j);
       }
     }
+    // stores count in vmcnt on gfx950: a wait for a residual row that was requested after a store is a wait for that store.  So the
+    // pass's residual rows are all requested HERE, before its first store (the staged tiles' accumulators are dead by now), and the
+    // store loop below loads nothing
+    if (!g.R2) {
+      constexpr int KS = 4;
+      static_assert(NK % KS == 0, "row batches");
+      f32x4 q1[NK];
+      if (g.R1) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          int64_t m = row0 + p * EPT * 16 + rq + RPS * k;
+          m = m < g.M ? m : g.M - 1;
+          q1[k] = *(const f32x4*)(g.R1 + m * g.ldr1 + n);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) q1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k0 = 0; k0 < NK; k0 += KS) {
+        f32x4 o[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const int ml = rq + RPS * (k0 + k);
+          o[k] = *(const f32x4*)(stg + ml * NB + ((cl ^ (ml & 31)) << 2));
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const int ml = rq + RPS * (k0 + k);
+          const int64_t m = row0 + p * EPT * 16 + ml;
+          if (p * EPT * 16 + ml >= 16 * RT || m >= g.M) continue;
+          f32x4 v = o[k];
+          v[0] += g.r1_scale * q1[k0 + k][0] + 0.f, v[1] += g.r1_scale * q1[k0 + k][1] + 0.f;
+          v[2] += g.r1_scale * q1[k0 + k][2] + 0.f, v[3] += g.r1_scale * q1[k0 + k][3] + 0.f;
+          if (g.C) *(f32x4*)(g.C + m * g.ldc + n) = v;
+          if (g.C16) *(uint2*)(g.C16 + m * g.ldc + n) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
+        }
+      }
+      continue;
+    }
     __syncthreads();
     constexpr int KB = RT > 4 ? 2 : 4;  // rows per thread in flight (the accumulators of the later passes are still live)
 #pragma unroll
@@ -312,14 +353,16 @@ bool gemm_stream1_eligible(const GemmArgs& a) {
   return a.M > 0 && (int64_t)a.M * a.A.ld < (1ll << 31) && (int64_t)a.M * a.N < (1ll << 40);
 }
 
-// Where the streamed kernel is the faster one (tools/gemm_stream_bench.py, same process, 12544 / 6272 / 3136 / 1568 rows): up to 1024
-// output columns -- at 3072 / 4096 columns the grid is several rounds of 128 x 128 tiles and the tile kernel wins (155 vs 176 us);
-// with fp32 residual / output traffic both kernels sit on the same memory phase (52 us at 12544 x 1024 x 1024), so there only the
-// launches with few rows per CU, whose tile grid is a fraction of a round, are taken
+// Where the streamed kernel is the faster one (tools/gemm_stream_bench.py, same process, 12544 / 6272 / 3136 / 1568 rows x K = 1024;
+// profiles/r04_gemm_stream_bench*.txt): with a 16-bit-only epilogue everywhere up to 1024 columns (37 vs 45, 22 vs 24, 13 vs 16, 9 vs
+// 13.5 us) and at >= 10 000 rows for 3072 / 4096 columns (105 vs 109, 137 vs 151 us; at 6 272 rows the tile kernel wins, 60 vs 65);
+// with fp32 residual / output traffic both kernels sit on the same memory phase, and the streamed one is ahead only at the ends:
+// >= 10 000 rows (50 vs 52, 146 vs 159, 185 vs 216 us) and <= 2 000 rows (14.1 vs 15.4)
 bool gemm_stream1_wanted(const GemmArgs& a) {
-  if (!gemm_stream1_eligible(a) || a.N > 1024) return false;
+  if (!gemm_stream1_eligible(a)) return false;
   const bool light = !a.C && !a.R1 && !a.R2;
-  return light || a.M <= 4096;
+  if (a.M >= 10000) return true;
+  return light ? a.N <= 1024 : a.M <= 2000;
 }
 
 // tile shape: the largest (rows, columns) whose grid still covers ~3/4 of the CUs; a workgroup streams 32 NJ x K weight bytes
