@@ -281,6 +281,19 @@ __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
         *(uint2*)(g.C16_lo + (int64_t)m * g.ldc + n) = make_uint2(l0, l1);
       }
     } else {
+      // residual rows of this pass, all requested before its first store: stores count in vmcnt on gfx950 and the residual is often
+      // updated in place, so a load left inside the row loop waits for the previous row's stores (RP / 8 serial write round trips)
+      f32x4 q1[RP / 8], q2[RP / 8];
+      if (vec && (R1 || R2)) {
+#pragma unroll
+        for (int k = 0; k < RP / 8; ++k) {
+          int m = row0 + ps * RP + tid / TPR + 8 * k;
+          m = m < row_end ? m : row_end - 1;
+          const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
+          if (R1) q1[k] = *(const f32x4*)(R1 + mr * g.ldr1 + n);
+          if (R2) q2[k] = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < RP / 8; ++k) {
         const int ml = tid / TPR + 8 * k, m = row0 + ps * RP + ml;
@@ -289,11 +302,11 @@ __global__ __launch_bounds__(2 * BN3, 2) void gemm_x3_kernel(const GemmArgs g) {
         const int64_t mr = g.r1_mod ? (m % g.r1_mod) : m;
         if (vec) {
           if (R1) {
-            const f32x4 q = *(const f32x4*)(R1 + mr * g.ldr1 + n);
+            const f32x4 q = q1[k];
             v[0] += g.r1_scale * q[0], v[1] += g.r1_scale * q[1], v[2] += g.r1_scale * q[2], v[3] += g.r1_scale * q[3];
           }
           if (R2) {
-            const f32x4 q = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
+            const f32x4 q = q2[k];
             v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
           }
           if (C) *(f32x4*)(C + (int64_t)m * g.ldc + n) = v;

@@ -152,20 +152,41 @@ __device__ __forceinline__ void store_tile(const MdmMlpDesc& g, f32x4 (&y)[RT][N
         }
       }
     }
-    lds_barrier();
     constexpr int RPP = NT / CPR;  // rows per sweep of the workgroup
     const int cl = tid % CPR, n = 4 * cl;
+    // the pass's residual rows, all requested before its first store (stores count in vmcnt on gfx950 and the residual is usually
+    // updated in place: a load inside the row loop waits for the previous row's stores)
+    // (the 32- / 64-row forms of the dense pairs: that is where the residuals are; at RT = 7 and at the big widths the accumulators of
+    // the later passes leave no room for them -- 276 / 368 B of scratch -- and those launches have no residual)
+    constexpr bool PRE = RT <= 4 && NJ == 4;
+    f32x4 q1[PRE ? 16 * EPT / RPP : 1], q2[PRE ? 16 * EPT / RPP : 1];
+    if constexpr (PRE) {
+      if (R1 || R2) {
+#pragma unroll
+        for (int k = 0; k < 16 * EPT / RPP; ++k) {
+          int m = row0 + p * EPT * 16 + tid / CPR + RPP * k;
+          m = m < row_end ? m : row_end - 1;
+          if (R1) q1[k] = *(const f32x4*)(R1 + (int64_t)m * g.ldr1 + n);
+          if (R2) q2[k] = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
+        }
+      }
+    }
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < 16 * EPT / RPP; ++k) {
       const int ml = tid / CPR + RPP * k, tl = p * EPT * 16 + ml, m = row0 + tl;
       if (tl >= RT * 16 || m >= row_end) continue;
       f32x4 v = *(const f32x4*)(stg + ml * DOUT + ((cl ^ (ml & 31)) << 2));
       if (R1) {
-        const f32x4 q = *(const f32x4*)(R1 + (int64_t)m * g.ldr1 + n);
+        f32x4 q;
+        if constexpr (PRE) q = q1[k];
+        else q = *(const f32x4*)(R1 + (int64_t)m * g.ldr1 + n);
         v[0] += g.r1_scale * q[0], v[1] += g.r1_scale * q[1], v[2] += g.r1_scale * q[2], v[3] += g.r1_scale * q[3];
       }
       if (R2) {
-        const f32x4 q = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
+        f32x4 q;
+        if constexpr (PRE) q = q2[k];
+        else q = *(const f32x4*)(R2 + (int64_t)m * g.ldr2 + n);
         v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
       }
       if (KO == 6 && v[0] != 123.456f) continue;

@@ -188,18 +188,25 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
       *(f32x4*)(stg + ml * D + (((n >> 2) ^ (ml & 31)) << 2)) = v;
     }
   }
-  sg_barrier();
+  // the thread's residual pieces are all requested before its first store: the residual is usually updated in place (out == resid), so
+  // the compiler may not move a row's load above the previous row's store, and on gfx950 stores count in vmcnt -- left in the loop
+  // every row waited for the row before it to be written (8 serial write round trips per tile)
   const int cl = tid & 127, n = 4 * cl;
+  f32x4 q[SG_ROWS / 4];
+#pragma unroll
+  for (int k = 0; k < SG_ROWS / 4; ++k) {
+    int64_t m = row0 + (tid >> 7) + 4 * k;
+    m = m < g.M ? m : g.M - 1;
+    q[k] = g.resid ? *(const f32x4*)(g.resid + m * D + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  sg_barrier();
 #pragma unroll
   for (int k = 0; k < SG_ROWS / 4; ++k) {
     const int ml = (tid >> 7) + 4 * k;
     const int64_t m = row0 + ml;
     if (m >= g.M) continue;
     f32x4 v = *(const f32x4*)(stg + ml * D + ((cl ^ (ml & 31)) << 2));
-    if (g.resid) {
-      const f32x4 q = *(const f32x4*)(g.resid + m * D + n);
-      v[0] += q[0], v[1] += q[1], v[2] += q[2], v[3] += q[3];
-    }
+    if (g.resid) v[0] += q[k][0], v[1] += q[k][1], v[2] += q[k][2], v[3] += q[k][3];
     *(f32x4*)(g.out + m * D + n) = v;
     if (g.out16) *(uint2*)(g.out16 + m * D + n) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
   }
