@@ -325,8 +325,8 @@ def mode_table(a, m_main, inputs, host, diff, kw, dev, main_prec, main_ms, steps
             if live3 is not None:
                 res[3]["roofline"].update({
                     "achieved": round(live3[1] / live3[0] / 1e12, 2), "frac": round(live3[1] / live3[0] / PEAK[3], 4),
-                    "kernel": "gemm_x3_kernel<128, 128, 2, GELU | none> x 2: the expert MLP as its two grouped bf16x3 GEMMs (csrc/gemm3.hip), "
-                              "the dominant kernels of this mode",
+                    "kernel": "gemm_stream3_kernel<7, 512 | 1024, GELU | none> x 2: the expert MLP as its two grouped, streamed-weight bf16x3 "
+                              "GEMMs (csrc/gemm_stream3.hip), the dominant kernels of this mode",
                     "what": "mean algorithmic FLOP per expert-MLP launch pair (4 * routed rows * D * F) / mean duration of the pair, HIP "
                             "events on the launch stream inside real sampling steps (mdm_probe_*)",
                     "launch_us_mean": round(live3[0] * 1e6, 1), "launches_timed": len(live3[2]),
@@ -622,7 +622,8 @@ def main():
                 pmc_k = (pk["fetch_x2"] + pk["write"]) * 1e6 if pk else None
             rf = line["roofline"]
             x3 = a.precision == 3  # the fp32-grade mode runs the expert MLP as two grouped bf16x3 GEMMs; the probe brackets the pair
-            kname = ("gemm_x3_kernel<128, 128, 2, GELU | none> x 2 (the expert MLP as its two grouped bf16x3 GEMMs, csrc/gemm3.hip)" if x3
+            kname = ("gemm_stream3_kernel<7, 512 | 1024, GELU | none> x 2 (the expert MLP as its two grouped, streamed-weight bf16x3 GEMMs, "
+                     "csrc/gemm_stream3.hip)" if x3
                      else "fused_mlp_stream_kernel (expert W1-GELU-W2, csrc/mlp_stream.hip)")
             rf.update({"achieved": round(live[1] / live[0] / 1e12, 2), "frac": round(live[1] / live[0] / PEAK[a.precision], 4),
                        "traffic": None if x3 else pmc_k,
