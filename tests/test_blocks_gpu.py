@@ -408,3 +408,21 @@ def test_pre_split_rows_between_fp32_grade_gemms_change_nothing(B, S, N, precisi
             L.lib().mdm_set_gemm_variant(0)
         assert torch.isfinite(out).all()
         assert torch.equal(out, plain), (block, float((out - plain).abs().max()))
+
+
+@pytest.mark.parametrize("B,S", [(2, 98), (3, 196), (1, 5)])
+def test_fp32_grade_expert_gemms_on_the_streamed_kernel_change_nothing(B, S):
+    """csrc/gemm_stream3.hip inside the model (MdmPacked.ws of the expert matrices, fp32-grade mode): the MoE block and the whole
+    decoder layer must be bit-identical with the expert GEMM pair on the 128 x 128 tile kernel (knob 69) -- same products, same
+    order -- at group sizes from empty to several tiles (the router decides them)."""
+    m, sd, eph, proj, h, emb, xf, length, sc, pre, (D, H, E) = _setup(B, S, 28, 3)
+    L = pkg("_lib")
+    assert any(k.endswith("w1") for k in m.pack().wstream1), "the fp32-grade model packs pair streams for its expert matrices"
+    for block in (L.BLOCK_MOE, L.BLOCK_LAYER):
+        out = _run_block(m, block, h, sc, length, xf)
+        L.lib().mdm_set_gemm_variant(69)
+        try:
+            tile = _run_block(m, block, h, sc, length, xf)
+        finally:
+            L.lib().mdm_set_gemm_variant(0)
+        assert torch.isfinite(out).all() and torch.equal(out, tile)
