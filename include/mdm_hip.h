@@ -462,7 +462,8 @@ int mdm_add_i32(int32_t* dst, int32_t delta, void* stream);
  * LayerNorms / block tails behind it as their own launches, 62 fp32 rows instead of pre-split rows between the bf16x3 GEMMs;
  * streamed-weight GEMM (MdmGemmDesc.w_stream): 63 never, 68 wherever eligible, 64-67 the same with a forced tile shape (112 x 512,
  * 64 x 512, 64 x 256, 32 x 256); its bf16x3 form (pre-split rows x a pair stream): 69 never, 70 wherever eligible.
- * 41-49 (timing-only knock-outs and the stamped build of the fused expert MLP: outputs are WRONG under them) exist only in the
+ * 41-49 and 74-77 (timing-only knock-outs and the stamped build of the fused expert MLP, knock-outs of the fused stylization
+ * launch: outputs are WRONG under them) exist only in the
  * diagnostic library (-DMDM_DIAG: `python motiondiffusion-moe_amd/build.py --diag` -> libmdm_hip_diag.so, used by tools/mlp_ko.py
  * and tools/mlp_stamps.py); libmdm_hip.so returns MDM_ERR_ARG for them and leaves the knob unchanged. */
 int mdm_set_gemm_variant(int variant);

@@ -51,7 +51,7 @@ int mdm_set_gemm_variant(int v) {
 #ifndef MDM_DIAG
   // 41..49: knock-outs / stamped builds of the fused expert MLP whose outputs are wrong by construction.  They exist only in
   // the diagnostic library (-DMDM_DIAG, `build.py --diag`); the product library refuses the knob instead of computing garbage.
-  if (v >= 41 && v <= 49) return MDM_ERR_ARG;
+  if ((v >= 41 && v <= 49) || (v >= 74 && v <= 77)) return MDM_ERR_ARG;  // (74..77: knock-outs of the fused stylization launch)
 #endif
   mdm::g_bf16_variant = v;
   return MDM_OK;

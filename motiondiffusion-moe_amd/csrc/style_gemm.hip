@@ -56,6 +56,9 @@ struct StyleGemmArgs {
   float skip_scale;
   const float *l2w, *l2b;
   int ln_x2;  // ln_out as pre-split rows (MDM_OP_X2_ROW) for the GEMM that reads it, instead of fp32
+#ifdef MDM_DIAG
+  int ko;  // diagnostic library only (knobs 74..77, tools/style_ko.sh): 1 no row phase, 2 no K loop, 3 no output stores, 4 no weight refills
+#endif
 };
 
 template <typename HT, bool SRC16, int SG_RT>
@@ -77,6 +80,9 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
   for (int f = 0; f < 8; ++f) R[f] = *(const frag_t*)(wp + f * 1024);
 
   // ---- row phase (csrc/rowwise.hip style_in_rows, one wave per row) ------------------------------------------------------
+#ifdef MDM_DIAG
+  if (g.ko != 1)
+#endif
   {
     R8 pww, pbb, sww, sbb;
     if (g.pw) pww.load(g.pw, D, lane), pbb.load(g.pb, D, lane);
@@ -150,6 +156,12 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
     frag_t A[2][SG_RT];
 #pragma unroll
     for (int i = 0; i < SG_RT; ++i) A[0][i] = *(const frag_t*)(smem + xb + i * 16384);
+#ifdef MDM_DIAG
+    const int ksteps = g.ko == 2 ? 0 : 16;
+    const bool refill = g.ko != 4;
+#pragma unroll 1
+    for (int s0 = 0; s0 < ksteps; s0 += 16)
+#endif
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       if (s + 1 < 16) {
@@ -161,6 +173,9 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
         const int slot = (s * SG_NJ + j) & (NR - 1);
 #pragma unroll
         for (int i = 0; i < SG_RT; ++i) y[i][j] = HT::mfma16(R[slot], A[s & 1][i], y[i][j]);
+#ifdef MDM_DIAG
+        if (refill)
+#endif
         R[slot] = *(const frag_t*)(wp + slot * 1024);  // the last NR refills read (and discard) the next wave's / the padding
         if (slot == NR - 1) wp += NR * 1024;
       }
@@ -207,6 +222,9 @@ __global__ __launch_bounds__(SG_NT, (SG_RT <= 2 ? 4 : 2)) void style_gemm_kernel
     if (m >= g.M) continue;
     f32x4 v = *(const f32x4*)(stg + ml * D + ((cl ^ (ml & 31)) << 2));
     if (g.resid) v[0] += q[k][0], v[1] += q[k][1], v[2] += q[k][2], v[3] += q[k][3];
+#ifdef MDM_DIAG
+    if (g.ko == 3 && v[0] != 12345.678f) continue;
+#endif
     *(f32x4*)(g.out + m * D + n) = v;
     if (g.out16) *(uint2*)(g.out16 + m * D + n) = make_uint2(HT::pack(v[0], v[1]), HT::pack(v[2], v[3]));
   }
@@ -480,6 +498,9 @@ int style_gemm(const void* src, int src_fmt, int64_t M, int D, int S, const floa
   StyleGemmArgs g = {};
   g.src = src, g.M = M, g.S = S, g.pw = pw, g.pb = pb, g.sw = sw, g.sb = sb, g.sc = sc, g.pos4 = pos4, g.ws = ws, g.bias = bias;
   g.resid = resid, g.out_scale = out_scale, g.colscale = colscale, g.out = out, g.out16 = out16;
+#ifdef MDM_DIAG
+  g.ko = (g_bf16_variant >= 74 && g_bf16_variant <= 77) ? g_bf16_variant - 73 : 0;
+#endif
   // knob 29: 64-row tiles (one workgroup per CU, half the weight bytes per row) -- measured 1 % of a step SLOWER than two
   // co-resident 32-row workgroups per CU at 12544 rows; a row's arithmetic does not depend on the tile height
   if (g_bf16_variant == 29) return launch_style_gemm<4>(g, src_fmt != 0, h16, s);

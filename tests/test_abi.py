@@ -62,7 +62,7 @@ def test_product_library_refuses_the_diagnostic_knobs():
     lib = L.lib()
     assert lib.mdm_diag_build() == 0
     assert lib.mdm_set_gemm_variant(34) == 0
-    for v in range(41, 50):
+    for v in list(range(41, 50)) + list(range(74, 78)):  # (74..77: knock-outs of the fused stylization launch)
         assert lib.mdm_set_gemm_variant(v) == 1, v  # MDM_ERR_ARG
     assert lib.mdm_set_gemm_variant(0) == 0
     assert lib.mdm_diag_mlp_counters(None) == 3  # MDM_ERR_UNSUPPORTED
