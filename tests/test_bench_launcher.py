@@ -36,3 +36,26 @@ def test_single_rank_dry_run_needs_no_launcher():
 def test_mismatched_world_size_is_refused():
     r = _run(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_committed_traffic_is_reported_only_for_the_sources_it_was_measured_on(monkeypatch):
+    """bench.py prints roofline.traffic from profiles/r04_pmc_traffic_p<precision>.json only when the file carries the hash of the
+    kernel sources that are running; a profile of other sources is named as stale and not reported."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    f = os.path.join(root, "profiles", "r04_pmc_traffic_p1.json")
+    rec = json.load(open(f))
+    assert len(bench.source_sha16()) == 16 and rec.get("commit") and rec.get("src_sha16")
+    monkeypatch.setattr(bench, "source_sha16", lambda: rec["src_sha16"])
+    j, note = bench.committed_traffic(1)
+    assert j is not None and j["total_bytes_per_step"] == rec["total_bytes_per_step"] and rec["commit"] in note
+    monkeypatch.setattr(bench, "source_sha16", lambda: "0" * 16)
+    j, note = bench.committed_traffic(1)
+    assert j is None and "stale" in note
+    j, note = bench.committed_traffic(2)
+    assert j is None and "no counter profile" in note
